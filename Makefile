@@ -1,0 +1,49 @@
+# Build of the three shared libraries (no cmake: plain make + hipcc/g++).
+#   v-img_amd/lib/libvimg_hip.so   hand-written gfx950 kernels + C ABI   (the product)
+#   v-img_amd/lib/libvimg_host.so  host side: scene loading, SAH BVH, post (the product's host)
+#   oracle/liboracle.so            CPU restatement of the reference path  (test infrastructure)
+ROOT    := $(dir $(abspath $(lastword $(MAKEFILE_LIST))))
+HIPCC   ?= /opt/rocm/bin/hipcc
+CXX     ?= g++
+ARCH    ?= gfx950
+
+LIBDIR  := v-img_amd/lib
+HOSTSRC := $(wildcard v-img_amd/host/*.cpp)
+HOSTHDR := $(wildcard v-img_amd/host/*.hpp) $(wildcard include/*.h)
+HIPSRC  := $(wildcard v-img_amd/csrc/*.hip)
+HIPHDR  := $(wildcard v-img_amd/csrc/*.h) $(wildcard include/*.h)
+ORASRC  := $(wildcard oracle/*.cpp)
+ORAHDR  := $(wildcard oracle/*.h) $(wildcard include/*.h)
+
+# -ffp-contract=off everywhere: +,-,*,/,sqrt must round identically on CPU and GPU; fused
+# multiply-adds appear only where the reference writes std::fma.
+HOSTFLAGS := -std=c++20 -O2 -fPIC -shared -ffp-contract=off -fopenmp -Wall -Iinclude
+ORAFLAGS  := -std=c++20 -O3 -march=x86-64-v3 -fPIC -shared -ffp-contract=off -pthread -Wall -Iinclude
+HIPFLAGS  := --offload-arch=$(ARCH) -std=c++20 -O3 -fPIC -shared -ffp-contract=off \
+             -fno-fast-math -Iinclude -Wall -Wno-unused-function
+
+all: host hip oracle
+host: $(LIBDIR)/libvimg_host.so
+hip: $(LIBDIR)/libvimg_hip.so
+oracle: oracle/liboracle.so
+
+$(LIBDIR)/libvimg_host.so: $(HOSTSRC) $(HOSTHDR) Makefile
+	@mkdir -p $(LIBDIR)
+	$(CXX) $(HOSTFLAGS) $(HOSTSRC) -o $@
+
+$(LIBDIR)/libvimg_hip.so: $(HIPSRC) $(HIPHDR) Makefile
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) $(HIPSRC) -o $@
+
+oracle/liboracle.so: $(ORASRC) $(ORAHDR) Makefile
+	$(CXX) $(ORAFLAGS) $(ORASRC) -o $@
+
+# same oracle with the reference's own float libm calls (cosf, acosf ...) instead of the
+# double-evaluated forms the GPU can reproduce bit for bit; used by one CPU test.
+oracle/liboracle_libmf.so: $(ORASRC) $(ORAHDR) Makefile
+	$(CXX) $(ORAFLAGS) -DORACLE_LIBM_FLOAT=1 $(ORASRC) -o $@
+
+clean:
+	rm -f $(LIBDIR)/*.so oracle/*.so
+
+.PHONY: all host hip oracle clean

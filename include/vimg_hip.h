@@ -1,0 +1,97 @@
+/*
+ * vimg_hip.h — C ABI of libvimg_hip.so, the MI355X (gfx950) implementation of v-img's hot path.
+ *
+ * The reference has no FFI; its narrowest seam is the template call
+ *   std::vector<glm::vec3> scene_integrator(render_data, bvh, prims, lights, integrator)
+ *   (reference include/integrators.h:36-153, called from src/main.cpp:219-248)
+ * and its single-pixel twin trace_pixel (include/integrators.h:181-220, src/main.cpp:257-298).
+ * The entry points below replace exactly those two calls; INTEGRATION.md shows the binding a
+ * maintainer adds on the reference side.  Plain pointers and sizes only.
+ *
+ * Conventions: every function returns 0 on success and a negative VIMG_E_* code on failure;
+ * vimg_hip_last_error() returns the message for the calling thread's last failure.  Nothing
+ * throws across the ABI.  One device context per process (one process per GPU).
+ */
+#ifndef VIMG_HIP_H
+#define VIMG_HIP_H
+
+#include "vimg_scene.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  VIMG_OK = 0,
+  VIMG_E_INVALID = -1,     /* bad argument / inconsistent scene tables */
+  VIMG_E_DEVICE = -2,      /* HIP runtime error (no device, allocation, launch) */
+  VIMG_E_UNSUPPORTED = -3  /* integrator or feature not on the path */
+};
+
+typedef struct VimgDeviceScene VimgDeviceScene;   /* opaque: device-resident scene */
+
+/* Selects the GPU for this process (hipSetDevice) and creates the render stream. */
+int vimg_hip_init(int device_ordinal);
+
+/* Number of visible HIP devices, or a negative error code. */
+int vimg_hip_device_count(void);
+
+/* Validates the tables of `scene` (index ranges, BVH child ranges, stack bound), bakes them
+ * into the device layout described in DESIGN.md and copies them to HBM.  The host arrays may
+ * be freed afterwards.  Replaces nothing in the reference (its scene is already in RAM); it is
+ * the "load once" half of the seam so that the timed render starts with inputs resident. */
+int vimg_hip_scene_upload(const VimgScene* scene, VimgDeviceScene** out);
+int vimg_hip_scene_free(VimgDeviceScene* scene);
+
+/* Number of float triples a shard's compact framebuffer holds
+ * (= 64 * number of 8x8 tiles owned by tile_rank). */
+int64_t vimg_hip_shard_pixels(const VimgDeviceScene* scene, const VimgRenderParams* params);
+
+/* scene_integrator (reference include/integrators.h:36-153).
+ *  d_out_rgb : DEVICE pointer.
+ *      tile_world == 1: W*H float triples, linear radiance, index x + (H-1-y)*W, i.e. exactly
+ *                       the reference's image_accumulated vector (include/integrators.h:113,137).
+ *      tile_world  > 1: the shard's compact buffer, vimg_hip_shard_pixels() triples, tile-major
+ *                       ([local_tile][ty*8+tx]); assemble with vimg_hip_assemble_shards().
+ *  stream    : a hipStream_t cast to void*, or NULL for the library's own stream.
+ *  stats     : optional HOST pointer, filled when the call returns.
+ * The call enqueues the kernels and waits for them (the reference call is blocking too). */
+int vimg_hip_render(VimgDeviceScene* scene, const VimgRenderParams* params, void* d_out_rgb,
+                    void* stream, VimgRenderStats* stats);
+
+/* Same as vimg_hip_render but only enqueues (no host wait, no stats); used by bench.py to time
+ * back-to-back launches with HIP events on `stream`. */
+int vimg_hip_render_async(VimgDeviceScene* scene, const VimgRenderParams* params, void* d_out_rgb,
+                          void* stream);
+
+/* Convenience: tile_world must be 1; renders into an internal device buffer and copies the
+ * W*H*3 floats to out_rgb_host (what a reference maintainer would call from main.cpp). */
+int vimg_hip_render_to_host(VimgDeviceScene* scene, const VimgRenderParams* params,
+                            float* out_rgb_host, VimgRenderStats* stats);
+
+/* trace_pixel (reference include/integrators.h:181-220): one pixel (x, y), all samples;
+ * writes 3 floats to out_rgb_host. */
+int vimg_hip_trace_pixel(VimgDeviceScene* scene, const VimgRenderParams* params, int x, int y,
+                         float* out_rgb_host);
+
+/* De-interleaves `world` gathered compact shard buffers (concatenated in rank order, each
+ * padded to `shard_stride_pixels` triples) into the reference image layout.  d_shards and
+ * d_out_rgb are DEVICE pointers. */
+int vimg_hip_assemble_shards(const VimgDeviceScene* scene, uint32_t world,
+                             int64_t shard_stride_pixels, const void* d_shards, void* d_out_rgb,
+                             void* stream);
+
+/* Times `steps` back-to-back renders with hipEvents recorded on the launch stream.
+ * ms_per_launch[i] (host, `steps` floats) = duration of launch i.  Used for roofline.achieved. */
+int vimg_hip_time_renders(VimgDeviceScene* scene, const VimgRenderParams* params, void* d_out_rgb,
+                          int steps, float* ms_per_launch);
+
+/* Bytes of HBM the uploaded scene occupies. */
+int64_t vimg_hip_scene_bytes(const VimgDeviceScene* scene);
+
+const char* vimg_hip_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
