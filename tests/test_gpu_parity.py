@@ -1,0 +1,234 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Numerics bar: the kernels evaluate exactly the oracle's float/double expression tree
+(-ffp-contract=off both sides, IEEE divide/sqrt, same min/max selects); the only operations
+that are not bit-defined across the two are the double-precision libm/OCML transcendentals
+(cos, sin, acos, atan2, log, log2, pow), which both round to < 1 ulp (double) before the
+result is narrowed to float.  The tests therefore demand:
+  * bit-exact integers / indices (hit flags, primitive ids, ray counts),
+  * images: >= 99.9 % of pixels bit-identical and max |diff| <= 1e-5 relative on the rest at
+    test sizes (a last-bit difference in a transcendental can reroute a path; it is rare),
+  * unit probes: <= 2 ulp.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(scene):
+    from vimg_amd import hip
+    return hip.DeviceScene(scene)
+
+
+def _ulp_diff(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    ia = a.view(np.int32).astype(np.int64)
+    ib = b.view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, -(ia & 0x7FFFFFFF), ia)
+    ib = np.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
+    d = np.abs(ia - ib)
+    d[np.isnan(a) & np.isnan(b)] = 0
+    return d
+
+
+def _compare_images(gpu, cpu, what, min_exact=0.999, tol=1e-5):
+    assert gpu.shape == cpu.shape
+    exact = (gpu.view(np.uint32) == cpu.view(np.uint32)).all(axis=-1)
+    frac = exact.mean()
+    scale = max(1e-3, float(np.abs(cpu).max()))
+    maxdiff = float(np.abs(gpu.astype(np.float64) - cpu.astype(np.float64)).max())
+    print(f"{what}: bit-identical pixels {frac * 100:.4f} %, max |diff| {maxdiff:.3e}")
+    assert frac >= min_exact, f"{what}: only {frac * 100:.3f} % pixels bit-identical"
+    # pixels that differ must still be the same estimator: bounded by a few path contributions
+    assert np.abs(gpu.mean() - cpu.mean()) <= tol * scale + 1e-3 * abs(cpu.mean())
+
+
+SCENE_CASES = [
+    ("disney_spheres.json", (120, 56), 8, None),
+    ("glass_in_box.json", (96, 72), 8, None),
+    ("cornell_box_spheres.json", (80, 80), 8, None),
+    ("empty_box.json", (64, 64), 4, None),
+    ("MIS_light_tests/sphere_light_small_mis.json", (64, 64), 16, None),
+    ("MIS_light_tests/sphere_light_medium_mis.json", (64, 64), 16, None),
+]
+
+
+@pytest.mark.parametrize("name,res,spp,depth", SCENE_CASES)
+def test_image_matches_oracle_json_scenes(name, res, spp, depth):
+    s = scenes.json_scene(name, res=res)
+    p = s.default_params(samples=spp) if depth is None else s.default_params(samples=spp, depth=depth)
+    cpu, cst, _ = O.render(s, p)
+    d = _dev(s)
+    gpu, gst = d.render_to_host(p)
+    _compare_images(gpu, cpu, name)
+    # event counts are integers: every query of every path agrees except on re-routed paths
+    assert gst.paths == cst.paths
+    assert abs(gst.rays - cst.rays) <= max(4, 1e-4 * cst.rays)
+    assert gst.nan_samples == cst.nan_samples
+
+
+@pytest.mark.parametrize("integrator", ["s_normal", "g_normal"])
+def test_normal_integrators_bit_exact(integrator):
+    # BASELINE config 1: glass_in_box with the 'normal' integrator (no transcendental on the path)
+    s = scenes.json_scene("glass_in_box.json", res=(160, 120))
+    p = s.default_params(integrator=integrator, samples=8)
+    cpu, cst, _ = O.render(s, p)
+    gpu, gst = _dev(s).render_to_host(p)
+    assert np.array_equal(gpu.view(np.uint32), cpu.view(np.uint32))
+    assert gst.closest_rays == cst.closest_rays == gst.paths
+
+
+@pytest.mark.parametrize("envmap,lens", [(True, True), (False, False)])
+def test_feature_scene_matches_oracle(envmap, lens):
+    s = scenes.feature_scene(res=(96, 64), envmap=envmap, lens=lens)
+    p = s.default_params(samples=8, depth=10)
+    cpu, cst, _ = O.render(s, p)
+    gpu, gst = _dev(s).render_to_host(p)
+    _compare_images(gpu, cpu, f"feature(env={envmap},lens={lens})", min_exact=0.995)
+    assert abs(gst.rays - cst.rays) <= max(16, 1e-3 * cst.rays)
+
+
+def test_big_mesh_scene_full_stats():
+    s = scenes.big_mesh_scene(res=(128, 96))
+    p = s.default_params(samples=4, depth=8)
+    cpu, cst, _ = O.render(s, p)
+    gpu, gst = _dev(s).render_to_host(p)
+    _compare_images(gpu, cpu, "big mesh")
+    for k in ("closest_rays", "shadow_rays", "internal_visits", "leaf_visits", "prim_tests"):
+        a, b = getattr(gst, k), getattr(cst, k)
+        assert abs(a - b) <= max(64, 1e-3 * b), (k, a, b)
+
+
+def test_binned_bvh_and_ragged_resolution():
+    from vimg_amd import abi
+    s = scenes.json_scene("disney_spheres.json", res=(61, 37), bvh=abi.BVH_BINNED)   # not /8
+    p = s.default_params(samples=4)
+    cpu, _, _ = O.render(s, p)
+    gpu, _ = _dev(s).render_to_host(p)
+    _compare_images(gpu, cpu, "ragged 61x37 binned")
+
+
+def test_trace_pixel_matches_render_and_oracle():
+    s = scenes.json_scene("disney_spheres.json", res=(120, 56))
+    p = s.default_params(samples=8)
+    d = _dev(s)
+    img, _ = d.render_to_host(p)
+    for (x, y) in [(0, 0), (60, 28), (119, 55), (33, 10)]:
+        px = d.trace_pixel(p, x, y)
+        assert np.array_equal(px.view(np.uint32), img[56 - 1 - y, x].view(np.uint32))
+        ref = O.trace_pixel(s, p, x, y)
+        assert np.allclose(px, ref, rtol=1e-5, atol=1e-6)
+
+
+def test_probes_camera_hits_occlusion():
+    s = scenes.feature_scene(res=(96, 64))
+    d = _dev(s)
+    rng = np.random.default_rng(1)
+    n = 4096
+    cam_in = np.stack([rng.uniform(0, 96, n), rng.uniform(0, 64, n), rng.random(n), rng.random(n)],
+                      1).astype(np.float32)
+    cg, cc = d.probe(O.PROBE_CAMERA_RAY, cam_in), O.probe(s, O.PROBE_CAMERA_RAY, cam_in)
+    assert _ulp_diff(cg, cc).max() <= 2
+    rays = cc[:, :6]
+    hg, hc = d.probe(O.PROBE_CLOSEST_HIT, rays), O.probe(s, O.PROBE_CLOSEST_HIT, rays)
+    assert np.array_equal(hg[:, 0], hc[:, 0])            # hit / miss
+    assert np.array_equal(hg[:, 2:4], hc[:, 2:4])        # primitive, material ids
+    both = hc[:, 0] == 1
+    assert both.sum() > n // 2
+    assert _ulp_diff(hg[both][:, 1], hc[both][:, 1]).max() == 0          # t: no transcendental
+    assert _ulp_diff(hg[both][:, 4:13], hc[both][:, 4:13]).max() == 0    # p, n_s, n_g
+    assert _ulp_diff(hg[both][:, 13:26], hc[both][:, 13:26]).max() <= 4  # uv (acos/atan2), frame
+    occ_in = np.concatenate([hc[both][:, 4:7], -rays[both][:, 3:6],
+                             rng.uniform(0.1, 6, (both.sum(), 1)).astype(np.float32)], 1)
+    og, oc = d.probe(O.PROBE_OCCLUDED, occ_in), O.probe(s, O.PROBE_OCCLUDED, occ_in)
+    assert np.array_equal(og, oc)
+
+
+def test_probes_bsdf_and_lights():
+    s = scenes.feature_scene(res=(96, 64))
+    d = _dev(s)
+    rng = np.random.default_rng(2)
+    n = 4096
+    cam_in = np.stack([rng.uniform(0, 96, n), rng.uniform(0, 64, n), rng.random(n), rng.random(n)],
+                      1).astype(np.float32)
+    rays = O.probe(s, O.PROBE_CAMERA_RAY, cam_in)[:, :6]
+    wo = rng.normal(size=(n, 3)).astype(np.float32)
+    wo /= np.linalg.norm(wo, axis=1, keepdims=True)
+    ev_in = np.concatenate([rays, wo, rng.uniform(0, 0.02, (n, 2)).astype(np.float32),
+                            (rng.random((n, 1)) < 0.5).astype(np.float32)], 1)
+    eg, ec = d.probe(O.PROBE_BSDF_EVAL, ev_in), O.probe(s, O.PROBE_BSDF_EVAL, ev_in)
+    assert np.array_equal(eg[:, 0], ec[:, 0])
+    assert np.allclose(eg, ec, rtol=2e-5, atol=1e-7, equal_nan=True)
+    sm_in = np.concatenate([rays, rng.integers(0, 1 << 20, (n, 1)).astype(np.float32),
+                            (rng.random((n, 1)) < 0.5).astype(np.float32)], 1)
+    sg, sc = d.probe(O.PROBE_BSDF_SAMPLE, sm_in), O.probe(s, O.PROBE_BSDF_SAMPLE, sm_in)
+    assert np.array_equal(sg[:, :2], sc[:, :2])
+    assert np.allclose(sg, sc, rtol=2e-5, atol=1e-6)
+    li_in = np.concatenate([rng.uniform(-2, 2, (n, 3)).astype(np.float32),
+                            rng.integers(0, 1 << 20, (n, 1)).astype(np.float32)], 1)
+    lg, lc = d.probe(O.PROBE_LIGHT_SAMPLE, li_in), O.probe(s, O.PROBE_LIGHT_SAMPLE, li_in)
+    assert np.allclose(lg, lc, rtol=2e-5, atol=1e-7)
+    bg_in = np.concatenate([wo, rng.uniform(0, 0.05, (n, 2)).astype(np.float32)], 1)
+    bg, bc = d.probe(O.PROBE_BACKGROUND, bg_in), O.probe(s, O.PROBE_BACKGROUND, bg_in)
+    assert np.allclose(bg, bc, rtol=2e-5, atol=1e-7)
+
+
+def test_tile_shards_reassemble_to_the_single_gpu_image():
+    # image is independent of the number of shards by construction (per-pixel seeds)
+    import torch
+    from vimg_amd import dist as vdist
+    s = scenes.json_scene("disney_spheres.json", res=(123, 61))
+    d = _dev(s)
+    p1 = s.default_params(samples=4)
+    full, _ = d.render(p1)
+    for world in (2, 3, 8):
+        stride = vdist.shard_stride_pixels(123, 61, world)
+        gathered = torch.zeros((world, stride, 3), dtype=torch.float32, device="cuda")
+        paths = 0
+        for r in range(world):
+            pr = s.default_params(samples=4, tile_rank=r, tile_world=world)
+            _, st = d.render(pr, out=gathered[r])
+            paths += st.paths
+        assert paths == 123 * 61 * 4
+        img = d.assemble_shards(gathered, world, stride)
+        assert torch.equal(img, full)
+        host = vdist.assemble_numpy(gathered.cpu().numpy(), 123, 61, world)
+        assert np.array_equal(host, full.cpu().numpy())
+
+
+def test_full_size_properties_disney_spheres():
+    """BASELINE config 2 at full resolution, few samples: size-independent properties."""
+    s = scenes.json_scene("disney_spheres.json")
+    p = s.default_params(samples=4)
+    d = _dev(s)
+    img, st = d.render_to_host(p)
+    assert img.shape == (800, 1800, 3)
+    assert st.paths == 1800 * 800 * 4 and st.nan_samples == 0
+    assert np.isfinite(img).all() and img.min() >= 0
+    again, st2 = d.render_to_host(p)
+    assert np.array_equal(img, again) and st.rays == st2.rays        # deterministic
+    assert 5.5 < st.rays / st.paths < 6.0                              # SURVEY: 5.71 rays/path
+    # first hit on the light is exact: pixels looking at the emitter see exactly its radiance
+    assert np.any(np.all(img == 2.0, axis=-1))
+    # a single-pixel trace agrees with the oracle at full size
+    ref = O.trace_pixel(s, p, 900, 400)
+    assert np.allclose(d.trace_pixel(p, 900, 400), ref, rtol=1e-5, atol=1e-6)
+
+
+def test_error_paths():
+    from vimg_amd import hip
+    s = scenes.json_scene("disney_spheres.json", res=(32, 16))
+    d = _dev(s)
+    with pytest.raises(hip.HipError):
+        d.render_to_host(s.default_params(integrator="material"))
+    with pytest.raises(hip.HipError):
+        d.render_to_host(s.default_params(samples=0))
+    with pytest.raises(hip.HipError):
+        d.render_to_host(s.default_params(tile_rank=2, tile_world=2))
+    with pytest.raises(hip.HipError):
+        d.trace_pixel(s.default_params(), 32, 0)

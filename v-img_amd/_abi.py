@@ -206,5 +206,12 @@ def hip_lib():
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: run `make hip` (or __graft_entry__.build()); "
                                "there is no CPU fallback for the render path")
+        # One HIP runtime per process: the torch wheel ships its own libamdhip64 / ROCr, and a
+        # second copy in the same process cannot open the GPU.  Importing torch first makes the
+        # loader resolve our DT_NEEDED libamdhip64.so.7 to the copy torch already mapped.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _hip_lib = _bind(C.CDLL(path), HIP_SYMBOLS)
     return _hip_lib

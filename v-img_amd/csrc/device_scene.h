@@ -1,0 +1,115 @@
+// Device-resident scene layout (gfx950).  Built once by vimg_hip_scene_upload from the VimgScene
+// tables; every render reads only these arrays.
+//
+// Layout rules (DESIGN.md "Data layout in HBM"):
+//  * everything a lane fetches in one step is one 16-byte-aligned record read with dwordx4 loads;
+//    records that are always consumed together share a 64-byte line (BVH node = its own header +
+//    both child boxes; leaf primitive = everything the intersection test needs);
+//  * records are stored in the order traversal consumes them (leaf primitives in obj_indices
+//    order, so a leaf's primitives are consecutive);
+//  * the index chasing of the reference (obj_indices -> prims -> mesh -> indices -> vertices,
+//    include/bvh.h:152, include/geometry/triangle.h:75-79) is resolved at upload time.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vimg_scene.h"
+
+namespace vimg {
+
+// Explicit address spaces: pointers that live inside a by-value kernel argument are otherwise
+// generic and every access becomes a flat_* instruction (which also ties up the LDS counter).
+#define VIMG_GLOBAL __attribute__((address_space(1)))
+#define VIMG_LDS __attribute__((address_space(3)))
+template <typename T>
+using gptr = const VIMG_GLOBAL T*;
+// builtin vector types (unlike HIP's float4 class) can be loaded from any address space
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+
+// One BVH node, 64 B.  Internal: boxes of BOTH children (first_index, first_index+1) exactly as
+// BB_mins_maxes[2c+2 .. 2c+5] holds them (reference include/bvh.h:171-188); leaf: only `meta`.
+struct __attribute__((aligned(16))) DNode {
+  v4f a;         // Lmin.x Lmin.y Lmin.z Lmax.x
+  v4f b;         // Lmax.y Lmax.z Rmin.x Rmin.y
+  v4f c;         // Rmin.z Rmax.x Rmax.y Rmax.z
+  uint32_t first_index, obj_count, pad0, pad1;
+};
+static_assert(sizeof(DNode) == 64, "DNode must be one 64-byte line");
+
+// One leaf slot (position j of obj_indices), 48 B: all an intersection test reads.
+//  kind 0 triangle : v = p0 p1 p2          kind 2 degenerate triangle (never hit,
+//  kind 1 sphere   : v = centre, radius         include/geometry/triangle.h:86-92)
+struct __attribute__((aligned(16))) DLeafPrim {
+  v4f a, b;
+  float c0;
+  uint32_t prim;   // index into the reference's list_objects order
+  uint32_t kind;
+  uint32_t pad;
+};
+static_assert(sizeof(DLeafPrim) == 48, "DLeafPrim must be 48 bytes");
+
+// Per-triangle shading record, 64 B (positions again so hit_info needs no second indirection).
+struct __attribute__((aligned(16))) DTriShade {
+  float p[9];
+  uint32_t mesh;
+  uint32_t i0, i1, i2;   // global vertex ids (normals / uv lookup)
+  uint32_t pad[3];
+};
+static_assert(sizeof(DTriShade) == 64, "DTriShade must be 64 bytes");
+
+struct DScene {
+  // camera (TLCam members, reference src/tl_camera.cpp:6-23) — derived values computed on the host
+  float cam_to_world[16];
+  float p_size0, p_size1;
+  float cone_spread;        // raycone_for_primary_ray(...) is a per-render constant
+  float aperture_radius, focal_dist;
+  int32_t res_x, res_y;
+
+  // BVH
+  float root_min[3], root_max[3];
+  uint32_t num_nodes, max_depth;
+  gptr<DNode> nodes;
+  gptr<DLeafPrim> leaf_prims;
+
+  // primitives / shading data
+  gptr<VimgPrim> prims;
+  gptr<DTriShade> tri_shade;
+  gptr<VimgMesh> meshes;
+  gptr<float> normals;
+  gptr<float> uvs;
+  gptr<VimgSphere> spheres;
+  gptr<VimgMaterial> materials;
+  gptr<uint32_t> material_flags;   // MATF_* per material
+  gptr<VimgTexture> textures;
+  gptr<float> texels;
+  gptr<VimgTextureRG> rg_textures;
+  gptr<float> rg_texels;
+  gptr<VimgLight> lights;
+  uint32_t num_lights;
+  gptr<float> cdf_pool;
+  VimgBackground background;
+  uint32_t background_emissive;
+};
+
+enum : uint32_t {
+  MATF_NEEDS_UV = 1u,      // colour texture is not constant (checker / image) or RG / normal map
+  MATF_NEEDS_FRAME = 2u,   // Principled: reads HitInfo::n_frame
+};
+
+struct RenderArgs {
+  uint32_t integrator, samples, depth;
+  uint32_t tile_rank, tile_world;
+  uint32_t tiles_x, tiles_y;        // ceil(W/8), ceil(H/8)
+  uint32_t num_local_tiles;
+  uint32_t full_stats;
+  uint32_t stack_entries;           // per-lane LDS stack depth (max_depth + 2)
+  uint32_t lds_nodes;               // number of top-of-tree nodes staged into LDS
+  int32_t single_x, single_y;       // trace_pixel mode when >= 0
+};
+
+struct DeviceStats {
+  unsigned long long closest, shadow, internal, leaf, prim, nan_samples;
+};
+
+}  // namespace vimg

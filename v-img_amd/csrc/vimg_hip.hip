@@ -1,0 +1,650 @@
+// libvimg_hip.so — C ABI (include/vimg_hip.h) over the gfx950 kernels in render_kernels.h.
+// Host-side work here is limited to validating and baking the scene tables into the device
+// layout (once per scene) and launching kernels; there is no CPU render path in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numbers>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/vimg_hip.h"
+#include "render_kernels.h"
+
+using namespace vimg;
+
+namespace {
+
+thread_local std::string g_err;
+hipStream_t g_stream = nullptr;
+int g_device = -1;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(VIMG_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+}  // namespace
+
+struct VimgDeviceScene {
+  DScene d{};
+  std::vector<void*> allocs;
+  size_t total_bytes = 0;
+  bool textured = false;       // needs the TEX=true kernels (cones, image textures, env map)
+  uint32_t num_cus = 0;
+  // scratch owned by the scene: stats, work counter, host-render framebuffer
+  DeviceStats* d_stats = nullptr;
+  unsigned int* d_counter = nullptr;
+  float* d_frame = nullptr;
+  size_t frame_floats = 0;
+};
+
+namespace {
+
+template <typename T>
+int upload(VimgDeviceScene* s, const T* host, size_t count, const T** out) {
+  *out = nullptr;
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, bytes));
+  s->allocs.push_back(p);
+  s->total_bytes += bytes;
+  if (count) HIP_TRY(hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice));
+  *out = static_cast<const T*>(p);
+  return VIMG_OK;
+}
+
+// Shape checks so that no kernel ever indexes outside its tables.
+int validate(const VimgScene* sc) {
+  if (!sc) return fail(VIMG_E_INVALID, "scene is null");
+  if (sc->camera.res_x <= 0 || sc->camera.res_y <= 0) return fail(VIMG_E_INVALID, "bad resolution");
+  if (sc->num_prims == 0 || !sc->prims) return fail(VIMG_E_INVALID, "scene has no primitives");
+  const VimgBVH& b = sc->bvh;
+  if (b.num_nodes == 0 || !b.nodes || !b.bb_mins_maxes || !b.obj_indices)
+    return fail(VIMG_E_INVALID, "scene has no BVH");
+  if (b.max_depth + 2 > 96) return fail(VIMG_E_INVALID, "BVH deeper than the 94-level stack bound");
+  for (uint32_t i = 0; i < sc->num_prims; ++i) {
+    const VimgPrim& p = sc->prims[i];
+    if (p.type == VIMG_PRIM_TRIANGLE) {
+      if (p.index >= sc->num_tris) return fail(VIMG_E_INVALID, "prim: triangle index out of range");
+    } else if (p.type == VIMG_PRIM_SPHERE) {
+      if (p.index >= sc->num_spheres) return fail(VIMG_E_INVALID, "prim: sphere index out of range");
+    } else {
+      return fail(VIMG_E_INVALID, "prim: unknown type");
+    }
+  }
+  for (uint32_t t = 0; t < sc->num_tris; ++t) {
+    if (sc->tri_mesh[t] >= sc->num_meshes) return fail(VIMG_E_INVALID, "tri: mesh out of range");
+    const VimgMesh& m = sc->meshes[sc->tri_mesh[t]];
+    for (int k = 0; k < 3; ++k)
+      if (sc->tri_indices[t * 3 + k] >= m.num_vertices)
+        return fail(VIMG_E_INVALID, "tri: vertex index out of range");
+  }
+  for (uint32_t i = 0; i < sc->num_meshes; ++i) {
+    const VimgMesh& m = sc->meshes[i];
+    if (uint64_t(m.first_vertex) + m.num_vertices > sc->num_vertices)
+      return fail(VIMG_E_INVALID, "mesh: vertex range out of bounds");
+    if (m.material >= sc->num_materials) return fail(VIMG_E_INVALID, "mesh: material out of range");
+    if (m.num_uv_sets > VIMG_MAX_UV_SETS) return fail(VIMG_E_INVALID, "mesh: too many uv sets");
+    for (uint32_t k = 0; k < m.num_uv_sets; ++k)
+      if (uint64_t(m.uv_offset[k]) + m.num_vertices > sc->num_uvs)
+        return fail(VIMG_E_INVALID, "mesh: uv set out of bounds");
+    auto ok = [&](uint32_t u) { return u == VIMG_NO_UV || u < m.num_uv_sets; };
+    if (!ok(m.color_tex_uv) || !ok(m.normal_tex_uv) || !ok(m.metallic_roughness_tex_uv))
+      return fail(VIMG_E_INVALID, "mesh: uv selector out of range");
+  }
+  for (uint32_t i = 0; i < sc->num_spheres; ++i)
+    if (sc->spheres[i].material >= sc->num_materials)
+      return fail(VIMG_E_INVALID, "sphere: material out of range");
+  for (uint32_t i = 0; i < sc->num_textures; ++i) {
+    const VimgTexture& t = sc->textures[i];
+    if (t.type > VIMG_TEX_IMAGE) return fail(VIMG_E_INVALID, "texture: unknown type");
+    if (t.type == VIMG_TEX_IMAGE) {
+      if (t.num_levels == 0 || t.num_levels > VIMG_MAX_MIP_LEVELS || t.width == 0 || t.height == 0)
+        return fail(VIMG_E_INVALID, "texture: bad mip chain");
+      for (uint32_t l = 0; l < t.num_levels; ++l) {
+        uint64_t w = std::max(t.width >> l, 1u), h = std::max(t.height >> l, 1u);
+        if (t.level_offset[l] + w * h > sc->num_texels)
+          return fail(VIMG_E_INVALID, "texture: level out of bounds");
+      }
+    }
+  }
+  for (uint32_t i = 0; i < sc->num_rg_textures; ++i) {
+    const VimgTextureRG& t = sc->rg_textures[i];
+    if (t.width == 0 || t.height == 0 || t.wrap_u > 2 || t.wrap_v > 2)
+      return fail(VIMG_E_INVALID, "rg texture: bad size or wrap mode");
+    // the reference indexes the +x neighbours with "* height" (quirk Q6); for a non-square map
+    // that reads the wrong texel or runs off the image, so only square maps are accepted
+    if (t.width != t.height)
+      return fail(VIMG_E_UNSUPPORTED,
+                  "non-square metallic-roughness map: the reference reads outside the image there");
+    if (t.offset + uint64_t(t.width) * t.height > sc->num_rg_texels)
+      return fail(VIMG_E_INVALID, "rg texture out of bounds");
+  }
+  for (uint32_t i = 0; i < sc->num_materials; ++i) {
+    const VimgMaterial& m = sc->materials[i];
+    if (m.type > VIMG_MAT_PRINCIPLED) return fail(VIMG_E_INVALID, "material: unknown type");
+    auto tex_ok = [&](int32_t t) { return t >= -1 && t < int32_t(sc->num_textures); };
+    if (!tex_ok(m.tex) || !tex_ok(m.normal_map) || m.mr_tex < -1 ||
+        m.mr_tex >= int32_t(sc->num_rg_textures))
+      return fail(VIMG_E_INVALID, "material: texture index out of range");
+    if ((m.type == VIMG_MAT_LAMBERTIAN || m.type == VIMG_MAT_PRINCIPLED) && m.tex < 0)
+      return fail(VIMG_E_INVALID, "material: missing colour texture");
+    if (m.normal_map >= 0 && sc->textures[m.normal_map].type != VIMG_TEX_IMAGE)
+      return fail(VIMG_E_INVALID, "material: normal map must be an image");
+  }
+  for (uint32_t i = 0; i < sc->num_lights; ++i) {
+    const VimgLight& l = sc->lights[i];
+    if (l.type == VIMG_LIGHT_PRIM) {
+      if (l.prim >= sc->num_prims) return fail(VIMG_E_INVALID, "light: prim out of range");
+    } else if (l.type != VIMG_LIGHT_BACKGROUND) {
+      return fail(VIMG_E_INVALID, "light: unknown type");
+    }
+  }
+  if (sc->background.type == VIMG_BG_ENVMAP) {
+    const int32_t t = sc->background.env_tex;
+    if (t < 0 || t >= int32_t(sc->num_textures) || sc->textures[t].type != VIMG_TEX_IMAGE)
+      return fail(VIMG_E_INVALID, "background: env_tex must be an image texture");
+    const VimgTexture& img = sc->textures[t];
+    if (sc->background.row_cdf_offset + img.height + 1 > sc->num_cdf ||
+        sc->background.col_cdf_offset + uint64_t(img.height) * (img.width + 1) > sc->num_cdf)
+      return fail(VIMG_E_INVALID, "background: cdf out of bounds");
+  } else if (sc->background.type != VIMG_BG_CONST) {
+    return fail(VIMG_E_INVALID, "background: unknown type");
+  }
+  // BVH: every node reachable from the root exactly once, children and leaf ranges in bounds
+  std::vector<uint8_t> seen(b.num_nodes, 0);
+  std::vector<uint32_t> todo{0};
+  seen[0] = 1;
+  while (!todo.empty()) {
+    uint32_t n = todo.back();
+    todo.pop_back();
+    const VimgBVHNode& node = b.nodes[n];
+    if (node.obj_count != 0) {
+      if (uint64_t(node.first_index) + node.obj_count > sc->num_prims)
+        return fail(VIMG_E_INVALID, "bvh: leaf range out of bounds");
+      for (uint32_t i = 0; i < node.obj_count; ++i)
+        if (b.obj_indices[node.first_index + i] >= sc->num_prims)
+          return fail(VIMG_E_INVALID, "bvh: obj index out of range");
+    } else {
+      if (uint64_t(node.first_index) + 1 >= b.num_nodes || node.first_index == 0)
+        return fail(VIMG_E_INVALID, "bvh: child index out of range");
+      for (uint32_t c = node.first_index; c <= node.first_index + 1; ++c) {
+        if (seen[c]) return fail(VIMG_E_INVALID, "bvh: node reachable twice (not a tree)");
+        seen[c] = 1;
+        todo.push_back(c);
+      }
+    }
+  }
+  return VIMG_OK;
+}
+
+uint32_t tiles_of(int n) { return (static_cast<uint32_t>(n) + 7u) / 8u; }
+
+uint32_t local_tiles(const VimgDeviceScene* s, const VimgRenderParams* p) {
+  const uint32_t total = tiles_of(s->d.res_x) * tiles_of(s->d.res_y);
+  if (p->tile_rank >= total) return 0;
+  return (total - p->tile_rank + p->tile_world - 1) / p->tile_world;
+}
+
+int check_params(const VimgDeviceScene* s, const VimgRenderParams* p) {
+  if (!s || !p) return fail(VIMG_E_INVALID, "null scene or params");
+  if (p->tile_world == 0 || p->tile_rank >= p->tile_world)
+    return fail(VIMG_E_INVALID, "tile_rank must be < tile_world");
+  if (p->samples == 0) return fail(VIMG_E_INVALID, "samples must be > 0");
+  if (p->integrator == VIMG_INTEGRATOR_MATERIAL)
+    return fail(VIMG_E_UNSUPPORTED, "material integrator is not on the accelerated path");
+  if (p->integrator > VIMG_INTEGRATOR_MIS) return fail(VIMG_E_INVALID, "unknown integrator");
+  if (p->integrator == VIMG_INTEGRATOR_MIS && s->d.num_lights == 0)
+    return fail(VIMG_E_INVALID, "mis integrator needs at least one light (the reference's "
+                                "GroupOfEmitters::sample is undefined without one)");
+  return VIMG_OK;
+}
+
+struct LaunchCfg {
+  RenderArgs args;
+  uint32_t grid, lds_bytes;
+};
+
+LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int sx, int sy) {
+  LaunchCfg c{};
+  RenderArgs& a = c.args;
+  a.integrator = p->integrator;
+  a.samples = p->samples;
+  a.depth = p->depth;
+  a.tile_rank = p->tile_rank;
+  a.tile_world = p->tile_world;
+  a.tiles_x = tiles_of(s->d.res_x);
+  a.tiles_y = tiles_of(s->d.res_y);
+  a.num_local_tiles = local_tiles(s, p);
+  a.full_stats = 0;
+  a.stack_entries = s->d.max_depth + 2;
+  a.single_x = sx;
+  a.single_y = sy;
+  // LDS budget per 256-thread workgroup: stacks first, then as much of the top of the tree as
+  // fits in 40 KiB total (keeps >= 4 workgroups per CU inside the 160 KiB)
+  const uint32_t stack_bytes = 4u * a.stack_entries * 64u * 4u;
+  const uint32_t budget = 40u * 1024u;
+  uint32_t nodes = 0;
+  if (stack_bytes + 512 < budget) nodes = (budget - stack_bytes - 256) / 56u;
+  a.lds_nodes = std::min(nodes, s->d.num_nodes);
+  c.lds_bytes = ((a.lds_nodes * 56u + 255u) & ~255u) + stack_bytes;
+  // persistent grid: as many 4-wave workgroups as the kernel's registers and LDS let a CU hold
+  // (asked of the runtime), never more than the work
+  int per_cu = 0;
+  hipError_t oe = s->textured
+      ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<true>, 256, c.lds_bytes)
+      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<false>, 256, c.lds_bytes);
+  if (oe != hipSuccess || per_cu < 1) per_cu = 1;
+  const uint64_t items = (sx >= 0) ? 1 : uint64_t(a.num_local_tiles) * 64u;
+  const uint64_t need_blocks = (items + 255) / 256;
+  c.grid = static_cast<uint32_t>(
+      std::max<uint64_t>(1, std::min<uint64_t>(need_blocks, uint64_t(s->num_cus) * per_cu)));
+  return c;
+}
+
+int launch_render(VimgDeviceScene* s, const VimgRenderParams* p, float* d_out, hipStream_t st,
+                  bool full_stats, bool want_stats, int sx, int sy) {
+  LaunchCfg c = make_launch(s, p, sx, sy);
+  c.args.full_stats = full_stats ? 1u : 0u;
+  if (c.args.num_local_tiles == 0 && sx < 0) return VIMG_OK;
+  HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(unsigned int), st));
+  if (want_stats) HIP_TRY(hipMemsetAsync(s->d_stats, 0, sizeof(DeviceStats), st));
+  DeviceStats* stats = want_stats ? s->d_stats : nullptr;
+  if (s->textured)
+    hipLaunchKernelGGL(render_kernel<true>, dim3(c.grid), dim3(256), c.lds_bytes, st, s->d, c.args,
+                       d_out, stats, s->d_counter);
+  else
+    hipLaunchKernelGGL(render_kernel<false>, dim3(c.grid), dim3(256), c.lds_bytes, st, s->d, c.args,
+                       d_out, stats, s->d_counter);
+  HIP_TRY(hipGetLastError());
+  return VIMG_OK;
+}
+
+int fetch_stats(VimgDeviceScene* s, const VimgRenderParams* p, VimgRenderStats* out) {
+  DeviceStats ds{};
+  HIP_TRY(hipMemcpy(&ds, s->d_stats, sizeof(ds), hipMemcpyDeviceToHost));
+  *out = VimgRenderStats{};
+  out->closest_rays = ds.closest;
+  out->shadow_rays = ds.shadow;
+  out->internal_visits = ds.internal;
+  out->leaf_visits = ds.leaf;
+  out->prim_tests = ds.prim;
+  out->nan_samples = ds.nan_samples;
+  // pixels owned by this shard (ragged edge tiles counted exactly)
+  const uint32_t W = s->d.res_x, H = s->d.res_y, ty_n = tiles_of(H), total = tiles_of(W) * ty_n;
+  uint64_t px = 0;
+  for (uint32_t t = p->tile_rank; t < total; t += p->tile_world) {
+    uint32_t tx = t / ty_n, ty = t % ty_n;
+    px += uint64_t(std::min(8u, W - tx * 8)) * std::min(8u, H - ty * 8);
+  }
+  out->paths = px * p->samples;
+  return VIMG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vimg_hip_last_error(void) { return g_err.c_str(); }
+
+int vimg_hip_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(VIMG_E_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  return n;
+}
+
+int vimg_hip_init(int device_ordinal) {
+  HIP_TRY(hipSetDevice(device_ordinal));
+  if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+  g_device = device_ordinal;
+  return VIMG_OK;
+}
+
+int vimg_hip_scene_upload(const VimgScene* sc, VimgDeviceScene** out) {
+  if (!out) return fail(VIMG_E_INVALID, "null output pointer");
+  *out = nullptr;
+  if (g_device < 0) {
+    int rc = vimg_hip_init(0);
+    if (rc) return rc;
+  }
+  int rc = validate(sc);
+  if (rc) return rc;
+
+  auto* s = new VimgDeviceScene();
+  auto bail = [&](int code) {
+    vimg_hip_scene_free(s);
+    return code;
+  };
+  DScene& d = s->d;
+
+  // ---- camera: TLCam ctor (reference src/tl_camera.cpp:6-23) and the primary ray cone
+  // (include/ray.h:44-48) are per-render constants, evaluated here with the expressions the
+  // reference uses (tan is an unqualified call there: double)
+  const VimgCamera& cam = sc->camera;
+  std::memcpy(d.cam_to_world, cam.cam_to_world, sizeof(d.cam_to_world));
+  {
+    float theta = (cam.vfov_deg * std::numbers::pi) / 180.0;
+    float ratio = static_cast<float>(cam.res_x) / cam.res_y;
+    float img_height = 2.0f * (::tan(static_cast<double>(theta / 2.0f)));
+    d.p_size0 = ratio * img_height;
+    d.p_size1 = img_height;
+    float vfov = (cam.vfov_deg * std::numbers::pi) / 180.f;
+    // std::atan / std::tan of floats, evaluated in double and rounded once (DESIGN.md Numerics)
+    float t = static_cast<float>(::tan(static_cast<double>(vfov / 2.f)));
+    d.cone_spread = static_cast<float>(
+        ::atan(static_cast<double>(2.f * t / static_cast<float>(static_cast<uint32_t>(cam.res_y)))));
+  }
+  d.aperture_radius = cam.aperture_radius;
+  d.focal_dist = cam.focal_dist;
+  d.res_x = cam.res_x;
+  d.res_y = cam.res_y;
+
+  // ---- BVH: breadth-first renumbering (sibling pairs stay adjacent, root stays 0) so that the
+  // lowest indices are the top of the tree — the part staged into LDS.  Traversal order depends
+  // on the tree, not on the numbering, so results are unchanged.
+  const VimgBVH& b = sc->bvh;
+  std::vector<uint32_t> order;   // new index -> old index
+  order.reserve(b.num_nodes);
+  order.push_back(0);
+  std::vector<uint32_t> new_of(b.num_nodes, 0);
+  for (size_t head = 0; head < order.size(); ++head) {
+    const VimgBVHNode& n = b.nodes[order[head]];
+    if (n.obj_count == 0) {
+      new_of[n.first_index] = static_cast<uint32_t>(order.size());
+      order.push_back(n.first_index);
+      new_of[n.first_index + 1] = static_cast<uint32_t>(order.size());
+      order.push_back(n.first_index + 1);
+    }
+  }
+  std::vector<DNode> nodes(order.size());
+  for (size_t i = 0; i < order.size(); ++i) {
+    const VimgBVHNode& n = b.nodes[order[i]];
+    DNode dn{};
+    dn.obj_count = n.obj_count;
+    if (n.obj_count != 0) {
+      dn.first_index = n.first_index;
+    } else {
+      dn.first_index = new_of[n.first_index];
+      const float* bb = b.bb_mins_maxes + (size_t(n.first_index) * 2 + 2) * 3;
+      const float* lmin = bb, *rmin = bb + 3, *lmax = bb + 6, *rmax = bb + 9;
+      dn.a = v4f{lmin[0], lmin[1], lmin[2], lmax[0]};
+      dn.b = v4f{lmax[1], lmax[2], rmin[0], rmin[1]};
+      dn.c = v4f{rmin[2], rmax[0], rmax[1], rmax[2]};
+    }
+    nodes[i] = dn;
+  }
+  for (int a = 0; a < 3; ++a) {
+    d.root_min[a] = b.bb_mins_maxes[0 * 3 + a];
+    d.root_max[a] = b.bb_mins_maxes[2 * 3 + a];
+  }
+  d.num_nodes = static_cast<uint32_t>(nodes.size());
+  d.max_depth = b.max_depth;
+
+  // ---- per-triangle shading records and leaf slots
+  std::vector<DTriShade> shade(sc->num_tris);
+  for (uint32_t t = 0; t < sc->num_tris; ++t) {
+    const VimgMesh& m = sc->meshes[sc->tri_mesh[t]];
+    DTriShade ts{};
+    ts.mesh = sc->tri_mesh[t];
+    ts.i0 = m.first_vertex + sc->tri_indices[t * 3 + 0];
+    ts.i1 = m.first_vertex + sc->tri_indices[t * 3 + 1];
+    ts.i2 = m.first_vertex + sc->tri_indices[t * 3 + 2];
+    const uint32_t ids[3] = {ts.i0, ts.i1, ts.i2};
+    for (int k = 0; k < 3; ++k)
+      for (int a = 0; a < 3; ++a) ts.p[k * 3 + a] = sc->vertices[size_t(ids[k]) * 3 + a];
+    shade[t] = ts;
+  }
+  std::vector<DLeafPrim> leaf(sc->num_prims);
+  for (uint32_t j = 0; j < sc->num_prims; ++j) {
+    const uint32_t prim = b.obj_indices[j];
+    const VimgPrim& p = sc->prims[prim];
+    DLeafPrim lp{};
+    lp.prim = prim;
+    if (p.type == VIMG_PRIM_TRIANGLE) {
+      const float* v = shade[p.index].p;
+      lp.a = v4f{v[0], v[1], v[2], v[3]};
+      lp.b = v4f{v[4], v[5], v[6], v[7]};
+      lp.c0 = v[8];
+      // the degenerate-triangle reject of the reference (triangle.h:86-92) depends on the
+      // vertices only: evaluate it once, with the same float expression
+      float e1[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]};
+      float e2[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
+      float cx = e2[1] * e1[2] - e1[1] * e2[2];
+      float cy = e2[2] * e1[0] - e1[2] * e2[0];
+      float cz = e2[0] * e1[1] - e1[0] * e2[1];
+      float l2 = cx * cx + cy * cy + cz * cz;
+      lp.kind = (l2 == 0.f) ? 2u : 0u;
+    } else {
+      const VimgSphere& sp = sc->spheres[p.index];
+      lp.a = v4f{sp.center[0], sp.center[1], sp.center[2], sp.radius};
+      lp.kind = 1u;
+    }
+    leaf[j] = lp;
+  }
+
+  // ---- material flags / kernel variant
+  std::vector<uint32_t> mflags(sc->num_materials, 0);
+  bool textured = (sc->background.type == VIMG_BG_ENVMAP);
+  for (uint32_t i = 0; i < sc->num_materials; ++i) {
+    const VimgMaterial& m = sc->materials[i];
+    uint32_t f = 0;
+    if (m.type == VIMG_MAT_PRINCIPLED) f |= MATF_NEEDS_FRAME;
+    if (m.tex >= 0 && sc->textures[m.tex].type != VIMG_TEX_CONST) f |= MATF_NEEDS_UV;
+    if (m.tex >= 0 && sc->textures[m.tex].type == VIMG_TEX_IMAGE) textured = true;
+    if (m.mr_tex >= 0 || m.normal_map >= 0) {
+      f |= MATF_NEEDS_UV;
+      textured = true;
+    }
+    mflags[i] = f;
+  }
+  s->textured = textured;
+
+#define UP(field, host, count)                                                     \
+  do {                                                                             \
+    const std::remove_cv_t<std::remove_pointer_t<decltype(host)>>* p_ = nullptr;   \
+    int rc_ = upload(s, host, count, &p_);                                         \
+    if (rc_) return bail(rc_);                                                     \
+    d.field = (decltype(d.field))p_;                                               \
+  } while (0)
+  UP(nodes, nodes.data(), nodes.size());
+  UP(leaf_prims, leaf.data(), leaf.size());
+  UP(prims, sc->prims, sc->num_prims);
+  UP(tri_shade, shade.data(), shade.size());
+  UP(meshes, sc->meshes, sc->num_meshes);
+  UP(normals, sc->normals, size_t(sc->num_vertices) * 3);
+  UP(uvs, sc->uvs, sc->num_uvs * 2);
+  UP(spheres, sc->spheres, sc->num_spheres);
+  UP(materials, sc->materials, sc->num_materials);
+  UP(material_flags, mflags.data(), mflags.size());
+  UP(textures, sc->textures, sc->num_textures);
+  UP(texels, sc->texels, sc->num_texels * 3);
+  UP(rg_textures, sc->rg_textures, sc->num_rg_textures);
+  UP(rg_texels, sc->rg_texels, sc->num_rg_texels * 2);
+  UP(lights, sc->lights, sc->num_lights);
+  UP(cdf_pool, sc->cdf_pool, sc->num_cdf);
+#undef UP
+  d.num_lights = sc->num_lights;
+  d.background = sc->background;
+  // Background::is_emissive (reference include/background.h:51-56,176)
+  d.background_emissive = (sc->background.type == VIMG_BG_ENVMAP) ||
+                          !(sc->background.col[0] == 0.f && sc->background.col[1] == 0.f &&
+                            sc->background.col[2] == 0.f);
+
+  hipDeviceProp_t prop{};
+  if (hipGetDeviceProperties(&prop, g_device) != hipSuccess) return bail(fail(VIMG_E_DEVICE, "hipGetDeviceProperties failed"));
+  s->num_cus = static_cast<uint32_t>(prop.multiProcessorCount);
+  if (hipMalloc(reinterpret_cast<void**>(&s->d_stats), sizeof(DeviceStats)) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&s->d_counter), sizeof(unsigned int)) != hipSuccess)
+    return bail(fail(VIMG_E_DEVICE, "hipMalloc of scratch failed"));
+  *out = s;
+  return VIMG_OK;
+}
+
+int vimg_hip_scene_free(VimgDeviceScene* s) {
+  if (!s) return VIMG_OK;
+  for (void* p : s->allocs) (void)hipFree(p);
+  if (s->d_stats) (void)hipFree(s->d_stats);
+  if (s->d_counter) (void)hipFree(s->d_counter);
+  if (s->d_frame) (void)hipFree(s->d_frame);
+  delete s;
+  return VIMG_OK;
+}
+
+int64_t vimg_hip_scene_bytes(const VimgDeviceScene* s) {
+  return s ? static_cast<int64_t>(s->total_bytes) : 0;
+}
+
+int64_t vimg_hip_shard_pixels(const VimgDeviceScene* s, const VimgRenderParams* p) {
+  int rc = check_params(s, p);
+  if (rc) return rc;
+  return int64_t(local_tiles(s, p)) * 64;
+}
+
+int vimg_hip_render_async(VimgDeviceScene* s, const VimgRenderParams* p, void* d_out, void* stream) {
+  int rc = check_params(s, p);
+  if (rc) return rc;
+  if (!d_out) return fail(VIMG_E_INVALID, "null output pointer");
+  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : g_stream;
+  return launch_render(s, p, static_cast<float*>(d_out), st, false, false, -1, -1);
+}
+
+int vimg_hip_render(VimgDeviceScene* s, const VimgRenderParams* p, void* d_out, void* stream,
+                    VimgRenderStats* stats) {
+  int rc = check_params(s, p);
+  if (rc) return rc;
+  if (!d_out) return fail(VIMG_E_INVALID, "null output pointer");
+  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : g_stream;
+  rc = launch_render(s, p, static_cast<float*>(d_out), st, stats != nullptr, stats != nullptr, -1, -1);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(st));
+  if (stats) return fetch_stats(s, p, stats);
+  return VIMG_OK;
+}
+
+int vimg_hip_render_to_host(VimgDeviceScene* s, const VimgRenderParams* p, float* out_host,
+                            VimgRenderStats* stats) {
+  int rc = check_params(s, p);
+  if (rc) return rc;
+  if (!out_host) return fail(VIMG_E_INVALID, "null output pointer");
+  if (p->tile_world != 1) return fail(VIMG_E_INVALID, "render_to_host needs tile_world == 1");
+  const size_t floats = size_t(s->d.res_x) * s->d.res_y * 3;
+  if (s->frame_floats < floats) {
+    if (s->d_frame) (void)hipFree(s->d_frame);
+    s->d_frame = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_frame), floats * sizeof(float)));
+    s->frame_floats = floats;
+  }
+  rc = vimg_hip_render(s, p, s->d_frame, nullptr, stats);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(out_host, s->d_frame, floats * sizeof(float), hipMemcpyDeviceToHost));
+  return VIMG_OK;
+}
+
+int vimg_hip_trace_pixel(VimgDeviceScene* s, const VimgRenderParams* p, int x, int y,
+                         float* out_host) {
+  int rc = check_params(s, p);
+  if (rc) return rc;
+  if (!out_host || x < 0 || y < 0 || x >= s->d.res_x || y >= s->d.res_y)
+    return fail(VIMG_E_INVALID, "trace_pixel: pixel out of range");
+  if (s->frame_floats < 3) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_frame), 3 * sizeof(float)));
+    s->frame_floats = 3;
+  }
+  rc = launch_render(s, p, s->d_frame, g_stream, false, false, x, y);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(g_stream));
+  HIP_TRY(hipMemcpy(out_host, s->d_frame, 3 * sizeof(float), hipMemcpyDeviceToHost));
+  return VIMG_OK;
+}
+
+int vimg_hip_assemble_shards(const VimgDeviceScene* s, uint32_t world, int64_t shard_stride_pixels,
+                             const void* d_shards, void* d_out, void* stream) {
+  if (!s || !d_shards || !d_out || world == 0) return fail(VIMG_E_INVALID, "assemble: bad arguments");
+  const uint32_t tx = tiles_of(s->d.res_x), ty = tiles_of(s->d.res_y);
+  const uint64_t max_local = (uint64_t(tx) * ty + world - 1) / world;
+  if (shard_stride_pixels < int64_t(max_local * 64))
+    return fail(VIMG_E_INVALID, "assemble: shard stride smaller than the largest shard");
+  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : g_stream;
+  const uint32_t threads = tx * ty * 64;
+  hipLaunchKernelGGL(assemble_kernel, dim3((threads + 255) / 256), dim3(256), 0, st,
+                     static_cast<const float*>(d_shards), static_cast<float*>(d_out),
+                     uint32_t(s->d.res_x), uint32_t(s->d.res_y), tx, ty, world,
+                     static_cast<long long>(shard_stride_pixels));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));
+  return VIMG_OK;
+}
+
+int vimg_hip_time_renders(VimgDeviceScene* s, const VimgRenderParams* p, void* d_out, int steps,
+                          float* ms_per_launch) {
+  int rc = check_params(s, p);
+  if (rc) return rc;
+  if (!d_out || steps <= 0 || !ms_per_launch) return fail(VIMG_E_INVALID, "time_renders: bad arguments");
+  std::vector<hipEvent_t> ev(size_t(steps) * 2);
+  for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+  for (int i = 0; i < steps; ++i) {
+    // the counter reset is part of a launch's prologue; the events bracket the kernel only
+    HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(unsigned int), g_stream));
+    LaunchCfg c = make_launch(s, p, -1, -1);
+    HIP_TRY(hipEventRecord(ev[2 * i], g_stream));
+    if (s->textured)
+      hipLaunchKernelGGL(render_kernel<true>, dim3(c.grid), dim3(256), c.lds_bytes, g_stream, s->d,
+                         c.args, static_cast<float*>(d_out), static_cast<DeviceStats*>(nullptr),
+                         s->d_counter);
+    else
+      hipLaunchKernelGGL(render_kernel<false>, dim3(c.grid), dim3(256), c.lds_bytes, g_stream, s->d,
+                         c.args, static_cast<float*>(d_out), static_cast<DeviceStats*>(nullptr),
+                         s->d_counter);
+    HIP_TRY(hipEventRecord(ev[2 * i + 1], g_stream));
+  }
+  HIP_TRY(hipStreamSynchronize(g_stream));
+  for (int i = 0; i < steps; ++i) HIP_TRY(hipEventElapsedTime(&ms_per_launch[i], ev[2 * i], ev[2 * i + 1]));
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return VIMG_OK;
+}
+
+// Unit-level probe (declared here, not in vimg_hip.h: it is a test hook, not part of the seam).
+int vimg_hip_probe(VimgDeviceScene* s, int kind, int n, const float* in_host, float* out_host) {
+  static const int n_in[8] = {0, 4, 6, 7, 12, 8, 4, 5};
+  static const int n_out[8] = {0, 8, 28, 1, 5, 7, 10, 4};
+  if (!s || kind < 1 || kind > 7 || n <= 0 || !in_host || !out_host)
+    return fail(VIMG_E_INVALID, "probe: bad arguments");
+  float *d_in = nullptr, *d_out = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_in), size_t(n) * n_in[kind] * sizeof(float)));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), size_t(n) * n_out[kind] * sizeof(float)));
+  HIP_TRY(hipMemcpy(d_in, in_host, size_t(n) * n_in[kind] * sizeof(float), hipMemcpyHostToDevice));
+  VimgRenderParams p{VIMG_INTEGRATOR_MIS, 1, 1, 0, 1};
+  LaunchCfg c = make_launch(s, &p, -1, -1);
+  const uint32_t grid = (uint32_t(n) + 255) / 256;
+  if (s->textured)
+    hipLaunchKernelGGL(probe_kernel<true>, dim3(grid), dim3(256), c.lds_bytes, g_stream, s->d, c.args,
+                       kind, n, d_in, d_out);
+  else
+    hipLaunchKernelGGL(probe_kernel<false>, dim3(grid), dim3(256), c.lds_bytes, g_stream, s->d, c.args,
+                       kind, n, d_in, d_out);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(g_stream));
+  HIP_TRY(hipMemcpy(out_host, d_out, size_t(n) * n_out[kind] * sizeof(float), hipMemcpyDeviceToHost));
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  return VIMG_OK;
+}
+
+}  // extern "C"

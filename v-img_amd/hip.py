@@ -1,0 +1,137 @@
+"""GPU side of the boundary: ctypes mirror of include/vimg_hip.h (libvimg_hip.so, gfx950).
+
+Mirrors the reference's hot-path entry points: ``render`` = scene_integrator
+(reference include/integrators.h:36-153), ``trace_pixel`` = trace_pixel (:181-220).
+torch is used only as the owner of device memory and streams; there is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as abi
+from .host import HostScene, make_params
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _lib():
+    return abi.hip_lib()
+
+
+def _check(rc):
+    if rc < 0:
+        raise HipError(f"[{rc}] " + _lib().vimg_hip_last_error().decode())
+    return rc
+
+
+def device_count():
+    return _check(_lib().vimg_hip_device_count())
+
+
+def init(device=0):
+    _check(_lib().vimg_hip_init(device))
+
+
+class DeviceScene:
+    """A scene resident in HBM (vimg_hip_scene_upload)."""
+
+    def __init__(self, host_scene: HostScene):
+        self._lib = _lib()
+        h = C.c_void_p()
+        _check(self._lib.vimg_hip_scene_upload(host_scene.view, C.byref(h)))
+        self._h = h
+        self.resolution = host_scene.resolution
+
+    @property
+    def bytes(self):
+        return int(self._lib.vimg_hip_scene_bytes(self._h))
+
+    def shard_pixels(self, params):
+        return _check(self._lib.vimg_hip_shard_pixels(self._h, C.byref(params)))
+
+    def render(self, params, out=None, stats=True, stream=None):
+        """Blocking render into a torch CUDA tensor (allocated when ``out`` is None).
+
+        tile_world == 1: returns [H, W, 3] in the reference layout (row 0 = top).
+        tile_world  > 1: returns the shard's compact [shard_pixels, 3] buffer."""
+        import torch
+        w, h = self.resolution
+        if out is None:
+            if params.tile_world == 1:
+                out = torch.empty((h, w, 3), dtype=torch.float32, device="cuda")
+            else:
+                out = torch.zeros((self.shard_pixels(params), 3), dtype=torch.float32,
+                                  device="cuda")
+        st = abi.RenderStats()
+        sp = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        _check(self._lib.vimg_hip_render(self._h, C.byref(params), C.c_void_p(out.data_ptr()), sp,
+                                         C.byref(st) if stats else None))
+        return (out, st) if stats else out
+
+    def render_async(self, params, out, stream=None):
+        sp = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        _check(self._lib.vimg_hip_render_async(self._h, C.byref(params),
+                                               C.c_void_p(out.data_ptr()), sp))
+
+    def render_to_host(self, params, stats=True):
+        """Render and copy the framebuffer to a numpy array [H, W, 3] (no torch needed)."""
+        w, h = self.resolution
+        out = np.empty((h, w, 3), dtype=np.float32)
+        st = abi.RenderStats()
+        _check(self._lib.vimg_hip_render_to_host(self._h, C.byref(params),
+                                                 out.ctypes.data_as(abi.Pf32),
+                                                 C.byref(st) if stats else None))
+        return (out, st) if stats else out
+
+    def trace_pixel(self, params, x, y):
+        out = np.zeros(3, dtype=np.float32)
+        _check(self._lib.vimg_hip_trace_pixel(self._h, C.byref(params), x, y,
+                                              out.ctypes.data_as(abi.Pf32)))
+        return out
+
+    def assemble_shards(self, gathered, world, shard_stride_pixels, out=None, stream=None):
+        import torch
+        w, h = self.resolution
+        if out is None:
+            out = torch.empty((h, w, 3), dtype=torch.float32, device="cuda")
+        sp = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        _check(self._lib.vimg_hip_assemble_shards(self._h, world, shard_stride_pixels,
+                                                  C.c_void_p(gathered.data_ptr()),
+                                                  C.c_void_p(out.data_ptr()), sp))
+        return out
+
+    def time_renders(self, params, out, steps):
+        ms = np.zeros(steps, dtype=np.float32)
+        _check(self._lib.vimg_hip_time_renders(self._h, C.byref(params),
+                                               C.c_void_p(out.data_ptr()), steps,
+                                               ms.ctypes.data_as(abi.Pf32)))
+        return ms
+
+    def probe(self, kind, inputs):
+        """Unit-level test hook (vimg_hip_probe); layouts as tests/oracle_lib.PROBE_IO."""
+        n_io = {1: (4, 8), 2: (6, 28), 3: (7, 1), 4: (12, 5), 5: (8, 7), 6: (4, 10), 7: (5, 4)}
+        fn = self._lib.vimg_hip_probe
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, abi.Pf32, abi.Pf32]
+        n_in, n_out = n_io[kind]
+        a = np.ascontiguousarray(inputs, dtype=np.float32).reshape(-1, n_in)
+        out = np.zeros((a.shape[0], n_out), dtype=np.float32)
+        _check(fn(self._h, kind, a.shape[0], a.ctypes.data_as(abi.Pf32),
+                  out.ctypes.data_as(abi.Pf32)))
+        return out
+
+    def close(self):
+        if self._h:
+            self._lib.vimg_hip_scene_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+__all__ = ["DeviceScene", "HipError", "device_count", "init", "make_params"]
