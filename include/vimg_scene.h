@@ -206,7 +206,8 @@ typedef struct VimgRenderStats {
   uint64_t shadow_rays;
   uint64_t internal_visits;
   uint64_t leaf_visits;
-  uint64_t prim_tests;
+  uint64_t prim_tests;       /* triangle + sphere intersection tests */
+  uint64_t sphere_tests;     /* the sphere share of prim_tests */
   uint64_t nan_samples;
 } VimgRenderStats;
 

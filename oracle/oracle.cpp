@@ -154,7 +154,7 @@ struct ScatterInfo {
 inline ScatterInfo no_scatter() { return ScatterInfo{vec3{0, 0, 0}, 0.f, false, false}; }
 
 struct Counters {
-  uint64_t closest = 0, shadow = 0, internal = 0, leaf = 0, prim = 0;
+  uint64_t closest = 0, shadow = 0, internal = 0, leaf = 0, prim = 0, sphere = 0;
 };
 
 // xform_with_onb / project_onto_onb / GramSchmidt / get_axis / init_onb
@@ -674,7 +674,10 @@ bool bvh_hit(const Ctx& c, Ray& ray, HitInfo* out) {
       for (uint32_t i = 0; i < node.obj_count; ++i) {
         uint32_t prim_index = bvh.obj_indices[node.first_index + i];
         const VimgPrim& p = s->prims[prim_index];
-        if (c.cnt) c.cnt->prim++;
+        if (c.cnt) {
+          c.cnt->prim++;
+          if (p.type == VIMG_PRIM_SPHERE) c.cnt->sphere++;
+        }
         ForHitInfo tmp{0.f, 0.f, 0.f, 0.f, prim_index, true};
         bool hit = (p.type == VIMG_PRIM_TRIANGLE) ? tri_hit(s, p.index, ray, &tmp)
                                                   : sphere_hit(s->spheres[p.index], ray);
@@ -1625,6 +1628,7 @@ int oracle_render(const VimgScene* scene, const VimgRenderParams* params, int nu
       stats->internal_visits += counters[t].internal;
       stats->leaf_visits += counters[t].leaf;
       stats->prim_tests += counters[t].prim;
+      stats->sphere_tests += counters[t].sphere;
       stats->nan_samples += nans[t];
     }
     uint64_t px = 0;

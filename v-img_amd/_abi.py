@@ -113,7 +113,7 @@ class RenderParams(C.Structure):
 class RenderStats(C.Structure):
     _fields_ = [("paths", u64), ("closest_rays", u64), ("shadow_rays", u64),
                 ("internal_visits", u64), ("leaf_visits", u64), ("prim_tests", u64),
-                ("nan_samples", u64)]
+                ("sphere_tests", u64), ("nan_samples", u64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

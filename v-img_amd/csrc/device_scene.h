@@ -109,7 +109,7 @@ struct RenderArgs {
 };
 
 struct DeviceStats {
-  unsigned long long closest, shadow, internal, leaf, prim, nan_samples;
+  unsigned long long closest, shadow, internal, leaf, prim, sphere, nan_samples;
 };
 
 }  // namespace vimg

@@ -130,7 +130,7 @@ struct Scatter {
 VD Scatter no_scatter() { return Scatter{f3{0.f, 0.f, 0.f}, 0.f, false, false}; }
 
 struct Counters {
-  uint32_t closest, shadow, internal, leaf, prim;
+  uint32_t closest, shadow, internal, leaf, prim, sphere;
 };
 
 // ONB helpers: reference include/hit_utils.h:32-59
@@ -521,6 +521,7 @@ VD bool traverse(const DScene& g, const Lds& L, TravRay& ray, HitRec& rec, Count
           hit = tri_test(f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c0}, ray, rc, t, e0, e1,
                          e2, idet);
         } else if (kind == 1) {
+          if (full_stats) cnt.sphere++;
           hit = sphere_test(f3{a.x, a.y, a.z}, a.w, ray, dir_len2, t);
         }
         if (hit) {
@@ -1425,7 +1426,7 @@ render_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
   const uint32_t total_items = single ? 1u : A.num_local_tiles * 64u;
   constexpr uint32_t roulette_threshold = 5;
 
-  Counters cnt{0, 0, 0, 0, 0};
+  Counters cnt{0, 0, 0, 0, 0, 0};
   uint32_t nan_samples = 0;
 
   // per-pixel state
@@ -1718,7 +1719,8 @@ render_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
     };
     unsigned long long c0 = wave_sum(cnt.closest), c1 = wave_sum(cnt.shadow),
                        c2 = wave_sum(cnt.internal), c3 = wave_sum(cnt.leaf),
-                       c4 = wave_sum(cnt.prim), c5 = wave_sum(nan_samples);
+                       c4 = wave_sum(cnt.prim), c5 = wave_sum(nan_samples),
+                       c6 = wave_sum(cnt.sphere);
     if (lane == 0) {
       atomicAdd(&stats->closest, c0);
       atomicAdd(&stats->shadow, c1);
@@ -1726,6 +1728,7 @@ render_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
         atomicAdd(&stats->internal, c2);
         atomicAdd(&stats->leaf, c3);
         atomicAdd(&stats->prim, c4);
+        atomicAdd(&stats->sphere, c6);
       }
       if (c5) atomicAdd(&stats->nan_samples, c5);
     }
@@ -1765,7 +1768,7 @@ probe_kernel(const DScene g, const RenderArgs A, int kind, int n, const float* _
   const Lds L = stage_lds(g, A, (VIMG_LDS unsigned char*)lds_raw);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Counters cnt{0, 0, 0, 0, 0};
+  Counters cnt{0, 0, 0, 0, 0, 0};
   auto trace = [&](const float* p, Hit& h, TravRay& tr) {
     tr = TravRay{f3{p[0], p[1], p[2]}, f3{p[3], p[4], p[5]}, 0.0001f, VIMG_INF};
     HitRec rec;

@@ -285,6 +285,7 @@ int fetch_stats(VimgDeviceScene* s, const VimgRenderParams* p, VimgRenderStats* 
   out->internal_visits = ds.internal;
   out->leaf_visits = ds.leaf;
   out->prim_tests = ds.prim;
+  out->sphere_tests = ds.sphere;
   out->nan_samples = ds.nan_samples;
   // pixels owned by this shard (ragged edge tiles counted exactly)
   const uint32_t W = s->d.res_x, H = s->d.res_y, ty_n = tiles_of(H), total = tiles_of(W) * ty_n;
