@@ -27,13 +27,16 @@ using gptr = const VIMG_GLOBAL T*;
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 
-// One BVH node, 64 B.  Internal: boxes of BOTH children (first_index, first_index+1) exactly as
-// BB_mins_maxes[2c+2 .. 2c+5] holds them (reference include/bvh.h:171-188); leaf: only `meta`.
+// One INTERNAL BVH node, 64 B: the boxes of both children exactly as BB_mins_maxes[2c+2 .. 2c+5]
+// holds them (reference include/bvh.h:171-188) and a reference to each child.  A child
+// reference packs "primitive count << 25 | index": count == 0 -> index of another DNode,
+// count > 0 -> a leaf whose primitives are leaf_prims[index .. index+count).  Leaves therefore
+// need no node record and no load of their own.
 struct __attribute__((aligned(16))) DNode {
   v4f a;         // Lmin.x Lmin.y Lmin.z Lmax.x
   v4f b;         // Lmax.y Lmax.z Rmin.x Rmin.y
   v4f c;         // Rmin.z Rmax.x Rmax.y Rmax.z
-  uint32_t first_index, obj_count, pad0, pad1;
+  uint32_t left_ref, right_ref, pad0, pad1;
 };
 static_assert(sizeof(DNode) == 64, "DNode must be one 64-byte line");
 
@@ -68,7 +71,8 @@ struct DScene {
 
   // BVH
   float root_min[3], root_max[3];
-  uint32_t num_nodes, max_depth;
+  uint32_t num_nodes, max_depth;   // num_nodes = internal nodes
+  uint32_t root_ref;               // packed reference of the root (a leaf for 1-node trees)
   gptr<DNode> nodes;
   gptr<DLeafPrim> leaf_prims;
 
@@ -110,6 +114,7 @@ struct RenderArgs {
 
 struct DeviceStats {
   unsigned long long closest, shadow, internal, leaf, prim, sphere, nan_samples;
+  unsigned long long trip_descend, trip_prim, iterations;   // wave-level loop trips (diagnostic)
 };
 
 }  // namespace vimg

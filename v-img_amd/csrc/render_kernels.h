@@ -131,7 +131,12 @@ VD Scatter no_scatter() { return Scatter{f3{0.f, 0.f, 0.f}, 0.f, false, false}; 
 
 struct Counters {
   uint32_t closest, shadow, internal, leaf, prim, sphere;
+  uint32_t trip_descend, trip_prim;   // wave-level loop trips (credited to the first active lane)
 };
+VD bool first_active_lane() {
+  const unsigned long long m = __ballot(1);
+  return (threadIdx.x & 63u) == static_cast<uint32_t>(__ffsll(static_cast<long long>(m)) - 1);
+}
 
 // ONB helpers: reference include/hit_utils.h:32-59
 VD f3 xform_with_onb(const Onb& o, f3 v) { return o.u * v.x + o.v * v.y + o.w * v.z; }
@@ -479,42 +484,108 @@ VD bool sphere_test(f3 center, float radius, const TravRay& r, float a, float& t
   return true;
 }
 
+// Fast form of the slab test for rays whose direction has no zero component: then no
+// (b - o) * inv product can be 0 * inf = NaN, and for NaN-free operands v_min/v_max return
+// exactly what the reference's (a<b)?b:a selects return (a +-0 difference cannot survive the
+// `max(..., minT)` with minT = 1e-4 > 0 nor flip the <= below).  One max3/min3 tree instead
+// of twelve compare+select pairs.
+VD float slab_fast(f3 bmin, f3 bmax, f3 o, f3 inv, float min_t, float max_t) {
+  f3 lower = (bmin - o) * inv;
+  f3 upper = (bmax - o) * inv;
+  float t_min = __builtin_fmaxf(
+      __builtin_fmaxf(__builtin_fminf(lower.x, upper.x), __builtin_fminf(lower.y, upper.y)),
+      __builtin_fmaxf(__builtin_fminf(lower.z, upper.z), min_t));
+  float t_max = __builtin_fminf(
+      __builtin_fminf(__builtin_fmaxf(lower.x, upper.x), __builtin_fmaxf(lower.y, upper.y)),
+      __builtin_fminf(__builtin_fmaxf(lower.z, upper.z), max_t));
+  return (t_min <= t_max) ? t_min : VIMG_INF;
+}
+
+// Child references: bits [31:25] = primitive count (0 = internal node), [24:0] = index of the
+// internal node, or of the leaf's first slot in leaf_prims.  Checked at upload.
+constexpr uint32_t REF_DONE = 0xffffffffu;
+VD uint32_t ref_count(uint32_t r) { return r >> 25; }
+VD uint32_t ref_index(uint32_t r) { return r & 0x1ffffffu; }
+
 // BVH::hit<T>: reference include/bvh.h:83-225.  Node visiting ORDER is the reference's: closest
 // hit descends into the nearer child first and keeps the farther one on the stack; any-hit
 // visits the second sibling first; a leaf tests its primitives in obj_indices order and, for
 // closest hit, the last success wins (ties at t == maxT included).
+//
+// Wave structure ("while-while"): all lanes first descend through internal nodes until each
+// holds a leaf (or is finished), then all lanes holding a leaf intersect it.  The box loop and
+// the primitive loop therefore each run with most lanes enabled, instead of every loop trip
+// paying for both bodies.
 template <bool ANY_HIT>
 VD bool traverse(const DScene& g, const Lds& L, TravRay& ray, HitRec& rec, Counters& cnt,
                  bool full_stats) {
   rec.prim = 0xffffffffu;
   const f3 inv{1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z};
+  // exact-select slab path only when 0 * inf is possible for this ray
+  const bool exact_slab = (ray.d.x == 0.f) || (ray.d.y == 0.f) || (ray.d.z == 0.f);
   float root = slab(load3k(g.root_min), load3k(g.root_max), ray.o, inv, ray.min_t, ray.max_t);
   if (is_inf(root)) return false;
   const TriRayConst rc = tri_ray_const(ray.d);
   const float dir_len2 = dot(ray.d, ray.d);
   uint32_t sp = 0;
-  uint32_t cur = 0;
-  for (;;) {
-    v4f na, nb, nc;
-    uint32_t first, count;
-    if (cur < L.n_nodes) {
-      v2u m = L.nm[cur];
-      first = m.x, count = m.y;
-      na = L.na[cur], nb = L.nb[cur], nc = L.nc[cur];
-    } else {
-      gptr<DNode> n = g.nodes + cur;
-      na = n->a, nb = n->b, nc = n->c;
-      first = n->first_index, count = n->obj_count;
+  uint32_t cur = g.root_ref;
+  bool found = false;
+  while (cur != REF_DONE) {
+    // ---- descend: box tests until this lane holds a leaf
+    while (cur != REF_DONE && ref_count(cur) == 0) {
+      v4f na, nb, nc;
+      v2u refs;
+      if (cur < L.n_nodes) {
+        na = L.na[cur], nb = L.nb[cur], nc = L.nc[cur];
+        refs = L.nm[cur];
+      } else {
+        gptr<DNode> n = g.nodes + cur;
+        na = n->a, nb = n->b, nc = n->c;
+        refs = v2u{n->left_ref, n->right_ref};
+      }
+      if (full_stats) {
+        cnt.internal++;
+        if (first_active_lane()) cnt.trip_descend++;
+      }
+      float h1, h2;
+      if (exact_slab) {
+        h1 = slab(f3{na.x, na.y, na.z}, f3{na.w, nb.x, nb.y}, ray.o, inv, ray.min_t, ray.max_t);
+        h2 = slab(f3{nb.z, nb.w, nc.x}, f3{nc.y, nc.z, nc.w}, ray.o, inv, ray.min_t, ray.max_t);
+      } else {
+        h1 = slab_fast(f3{na.x, na.y, na.z}, f3{na.w, nb.x, nb.y}, ray.o, inv, ray.min_t, ray.max_t);
+        h2 = slab_fast(f3{nb.z, nb.w, nc.x}, f3{nc.y, nc.z, nc.w}, ray.o, inv, ray.min_t, ray.max_t);
+      }
+      const bool in1 = !is_inf(h1), in2 = !is_inf(h2);
+      const uint32_t c1 = refs.x, c2 = refs.y;
+      if (in1 && in2) {
+        const bool first_is_near = ANY_HIT ? false : (h2 > h1);
+        const uint32_t near_c = first_is_near ? c1 : c2;
+        const uint32_t far_c = first_is_near ? c2 : c1;
+        L.stack[sp * 64] = far_c;
+        ++sp;
+        cur = near_c;
+      } else if (in1 || in2) {
+        cur = in1 ? c1 : c2;
+      } else if (sp != 0) {
+        --sp;
+        cur = L.stack[sp * 64];
+      } else {
+        cur = REF_DONE;
+      }
     }
-    bool have_next = false;
-    if (count != 0) {
+    // ---- intersect the leaf this lane holds
+    if (cur != REF_DONE) {
+      const uint32_t first = ref_index(cur), count = ref_count(cur);
       if (full_stats) cnt.leaf++;
       for (uint32_t i = 0; i < count; ++i) {
         gptr<DLeafPrim> lp = g.leaf_prims + (first + i);
         const v4f a = lp->a, b = lp->b;
         const float c0 = lp->c0;
         const uint32_t kind = lp->kind;
-        if (full_stats) cnt.prim++;
+        if (full_stats) {
+          cnt.prim++;
+          if (first_active_lane()) cnt.trip_prim++;
+        }
         bool hit = false;
         float t = 0.f, e0 = 0.f, e1 = 0.f, e2 = 0.f, idet = 0.f;
         if (kind == 0) {
@@ -526,42 +597,24 @@ VD bool traverse(const DScene& g, const Lds& L, TravRay& ray, HitRec& rec, Count
         }
         if (hit) {
           ray.max_t = t;
-          if (ANY_HIT) return true;
+          found = true;
+          if (ANY_HIT) break;
           rec.e0 = e0, rec.e1 = e1, rec.e2 = e2, rec.inv_det = idet;
           rec.prim = lp->prim;
           rec.kind = kind;
         }
       }
-    } else {
-      if (full_stats) cnt.internal++;
-      float h1 = slab(f3{na.x, na.y, na.z}, f3{na.w, nb.x, nb.y}, ray.o, inv, ray.min_t, ray.max_t);
-      float h2 = slab(f3{nb.z, nb.w, nc.x}, f3{nc.y, nc.z, nc.w}, ray.o, inv, ray.min_t, ray.max_t);
-      const bool in1 = !is_inf(h1), in2 = !is_inf(h2);
-      const uint32_t c1 = first, c2 = first + 1;
-      if (in1 && in2) {
-        uint32_t near_c, far_c;
-        if (ANY_HIT) {
-          near_c = c2, far_c = c1;
-        } else {
-          near_c = (h2 > h1) ? c1 : c2;
-          far_c = (h2 > h1) ? c2 : c1;
-        }
-        L.stack[sp * 64] = far_c;
-        ++sp;
-        cur = near_c;
-        have_next = true;
-      } else if (in1 || in2) {
-        cur = in1 ? c1 : c2;
-        have_next = true;
+      if (ANY_HIT && found) {
+        cur = REF_DONE;   // exit on first hit
+      } else if (sp != 0) {
+        --sp;
+        cur = L.stack[sp * 64];
+      } else {
+        cur = REF_DONE;
       }
     }
-    if (!have_next) {
-      if (sp == 0) break;
-      --sp;
-      cur = L.stack[sp * 64];
-    }
   }
-  return rec.prim != 0xffffffffu;
+  return found;
 }
 
 // ================================================================================ hit records
@@ -718,18 +771,6 @@ VD f3 mat_emitted(gptr<VimgMaterial> m, f3 ray_dir, f3 shading_normal) {
   return (dot(shading_normal, ray_dir) < 0) ? load3(m->emit) : f3{0.f, 0.f, 0.f};
 }
 
-// ---- Lambertian: reference src/material/lambertian.cpp:5-54
-VD Scatter lambertian_sample(const Hit& hit, f3 wi, Rng& rng) {
-  float rand1 = rand_float(rng);
-  float rand2 = rand_float(rng);
-  bool front_face = dot(wi, hit.ns) < 0;
-  f3 shading_normal = front_face ? hit.ns : -hit.ns;
-  Onb onb = init_onb(shading_normal);
-  f3 dir = xform_with_onb(onb, sample_hemisphere_cosine(rand1, rand2));
-  if (front_face) return Scatter{dir, 0.f, false, true};
-  return no_scatter();
-}
-
 // ---- Dielectric: reference src/material/dielectric.cpp:5-69
 VD f3 reflect_dir(f3 wi, f3 n) { return wi - (2.f * dot(wi, n) * n); }
 VD float schlick_apprx(float cosine, float in_ior, float out_ior) {
@@ -781,25 +822,66 @@ VD float g_w(f3 w, float alphax, float alphay, const Onb& frame) {
   float caret = (__builtin_sqrt(1. + static_cast<double>(vec_alpha)) - 1.) / 2.;
   return 1. / (1. + static_cast<double>(caret));
 }
-// anisotropic_sample_visible_normals: disney_common.h:16-52
-VD f3 sample_visible_normals(f3 local_dir_in, float alphax, float alphay, Rng& rng) {
-  float sign = 1.f;
-  f3 top = local_dir_in;
-  if (local_dir_in.z < 0.f) {
-    sign = -1.f;
-    top = -top;
-  }
-  f3 hemi_dir_in = normalize(f3{alphax * top.x, alphay * top.y, top.z});
-  float rand_x = rand_float(rng);
-  float rand_y = rand_float(rng);
-  float phi = 2 * kPi * rand_x;
-  float z = __builtin_fmaf((1.0f - rand_y), (1.0f + hemi_dir_in.z), -hemi_dir_in.z);
-  float sin_theta = sqrt_f(clampf(1.0f - z * z, 0.0f, 1.0f));
-  float x = sin_theta * ::cos(static_cast<double>(phi));
-  float y = sin_theta * ::sin(static_cast<double>(phi));
-  const f3 hemi_n = f3{x, y, z} + hemi_dir_in;
-  return sign * normalize(f3{alphax * hemi_n.x, alphay * hemi_n.y, sel_max(0.f, hemi_n.z)});
+// ---------------------------------------------------------------------------- BSDF sampling
+// Material::sample_mat for every material (virtual in the reference,
+// include/material/material.h:37-40), restated as ONE staged routine instead of one routine per
+// lobe.  All continuous lobes have the same skeleton — early-out tests, two rand_float draws, an
+// azimuth phi = 2*pi*r evaluated through cos/sin, a few lobe-specific lines — so a wave whose
+// lanes sit on different materials and lobes executes the expensive part (the RNG and the
+// double-precision sincos) once for everybody and only the short tails per lobe:
+//   Lambertian::sample_mat            src/material/lambertian.cpp:5-30
+//   Dielectric::sample_mat            src/material/dielectric.cpp:29-69
+//   Principled::sample_mat            src/material/principled.cpp:3-58
+//   sample_disney_diffuse             disney_diffuse.h:52-71
+//   sample_disney_clearcoat           disney_clearcoat.h:60-105
+//   sample_disney_metal               disney_metal.h:78-120
+//   sample_disney_rough_glass         disney_glass.h:108-186
+//   anisotropic_sample_visible_normals disney_common.h:16-52
+// The order of RNG draws of each branch is the reference's.
+
+// sin and cos of an azimuth in [0, 2*pi] (float 2*pi*r rounds to at most 6.2831855) in double.
+// Reduction by multiples of pi/2 (two-term Cody-Waite, k <= 4) and the fdlibm kernels; error
+// < 1 ulp(double), i.e. after narrowing to float the same value as libm's cos/sin in all but
+// ~1e-8 of arguments — the same statement that holds for OCML's routines, at a third of the cost.
+VD void sincos_azimuth(float phi_f, double& s_out, double& c_out) {
+  const double x = static_cast<double>(phi_f);
+  const double kd = __builtin_rint(x * 6.36619772367581382433e-01);
+  const int k = static_cast<int>(kd);
+  double r = __builtin_fma(-kd, 1.57079632673412561417e+00, x);
+  r = __builtin_fma(-kd, 6.07710050650619224932e-11, r);
+  const double z = r * r;
+  // __kernel_sin
+  double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+  ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+  ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+  const double sn = __builtin_fma(z * r, __builtin_fma(z, ps, -1.66666666666666324348e-01), r);
+  // __kernel_cos
+  double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+  pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+  pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+  pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+  const double hz = 0.5 * z;
+  const double wv = 1.0 - hz;
+  const double cs = wv + (((1.0 - wv) - hz) + z * (z * pc));
+  const bool swap = (k & 1) != 0;
+  double s = swap ? cs : sn;
+  double c = swap ? sn : cs;
+  if (k & 2) s = -s;
+  if ((k + 1) & 2) c = -c;
+  s_out = s, c_out = c;
 }
+
+enum : uint32_t {
+  LOBE_NONE = 0,      // no scatter (base class / early-out)
+  LOBE_COSINE = 1,    // cosine hemisphere about a frame: Lambertian and the Disney diffuse lobe
+  LOBE_CLEARCOAT = 2,
+  LOBE_METAL = 3,     // visible-normal sampling, reflect
+  LOBE_GLASS = 4,     // visible-normal sampling, Fresnel reflect/refract (one more draw)
+  LOBE_DIELECTRIC = 5
+};
+
 // fresnel_dielectric: disney_common.h:54-68
 VD float fresnel_dielectric(float n_dot_i, float eta) {
   float n_dot_t_sq = 1.f - (1.f - n_dot_i * n_dot_i) / (eta * eta);
@@ -998,72 +1080,142 @@ VD void principled_eval_pdf(const DScene& g, gptr<VimgMaterial> m, f3 wi,
   f_out = eval_principled;
 }
 
-// sample_disney_diffuse: disney_diffuse.h:52-71
-VD Scatter sample_disney_diffuse(f3 dir_in, const Hit& hit, const Onb& frame, Rng& rng) {
-  if (dot(hit.ng, dir_in) < 0) return no_scatter();
-  float rand1 = rand_float(rng);
-  float rand2 = rand_float(rng);
-  f3 dir_out = xform_with_onb(frame, sample_hemisphere_cosine(rand1, rand2));
-  if (dot(hit.ng, dir_out) <= 0) return no_scatter();
-  return Scatter{dir_out, 0.f, false, true};
-}
-// sample_disney_clearcoat + sample_local_h_clearcoat: disney_clearcoat.h:60-105
-VD Scatter sample_disney_clearcoat(f3 dir_in, const Hit& hit, Onb frame, float clearcoat_gloss,
-                                   Rng& rng, bool regularize) {
-  if (dot(hit.ng, dir_in) < 0) return no_scatter();
-  float alpha_g = (1.f - clearcoat_gloss) * 0.1f + clearcoat_gloss * 0.001f;
-  if (regularize && alpha_g < 0.1f) alpha_g = clampf(2.f * alpha_g, 0.03f, 0.1f);
-  const float alpha = alpha_g;
-  float rand1 = rand_float(rng);
-  float rand2 = rand_float(rng);
-  float cos2 = (1.f - ::pow(static_cast<double>(alpha * alpha), 1. - rand1)) / (1.f - (alpha * alpha));
-  float cos_elevation = sqrt_f(cos2);
-  float sin_elevation = sqrt_f(1 - cos2);
-  float h_azimuth = 2.f * kPi * rand2;
-  f3 local_h{sin_elevation * F_cos(h_azimuth), sin_elevation * F_sin(h_azimuth), cos_elevation};
-  if (dot(frame.w, dir_in) < 0) {
-    frame.u = -frame.u;
-    frame.v = -frame.v;
-    frame.w = -frame.w;
+template <bool TEX>
+VD Scatter sample_mat(const DScene& g, const Hit& hit, f3 wi, Rng& rng, bool regularize) {
+  gptr<VimgMaterial> m = g.materials + hit.mat;
+  const uint32_t type = m->type;
+  const f3 dir_in = -wi;
+  uint32_t lobe = LOBE_NONE;
+  Onb frame{f3{1.f, 0.f, 0.f}, f3{0.f, 1.f, 0.f}, f3{0.f, 0.f, 1.f}};
+  float alphax = 0.f, alphay = 0.f, eta = 0.f, alpha_g = 0.f;
+  bool lambert_front = true;
+
+  // ---- stage A: which lobe, its frame and parameters; early-outs that precede any draw
+  if (type == VIMG_MAT_LAMBERTIAN) {
+    lobe = LOBE_COSINE;   // draws first, front-face test afterwards (lambertian.cpp:7-29)
+    lambert_front = dot(wi, hit.ns) < 0;
+    frame = init_onb(lambert_front ? hit.ns : -hit.ns);
+  } else if (type == VIMG_MAT_DIELECTRIC) {
+    lobe = LOBE_DIELECTRIC;
+  } else if (type == VIMG_MAT_PRINCIPLED) {
+    const PrincipledCommon pc = principled_prologue<TEX>(g, m, wi, hit);
+    frame = pc.frame;
+    const float metallic = pc.metallic;
+    float roughness = pc.roughness;
+    const float ng_in = dot(hit.ng, dir_in);
+    if (ng_in < 0) {
+      lobe = LOBE_GLASS;   // inside the surface: glass only, no lobe draw (principled.cpp:23-26)
+    } else {
+      const float st = m->specular_transmission;
+      float diffuse_weight = (1.f - metallic) * (1.f - st);
+      float clearcoat_weight = 0.25f * m->clearcoat;
+      float metal_weight = (1.f - st * (1.f - metallic));
+      float glass_weight = (1.f - metallic) * st;
+      float total_w = diffuse_weight + clearcoat_weight + metal_weight + glass_weight;
+      float choose_diff = diffuse_weight / total_w;
+      float choose_clearcoat = clearcoat_weight / total_w;
+      float choose_metal = metal_weight / total_w;
+      float choose_glass = glass_weight / total_w;
+      float rnd = rand_float(rng);
+      if (rnd <= choose_diff) {
+        lobe = LOBE_COSINE;   // ng_in >= 0 here, so sample_disney_diffuse's early-out cannot fire
+      } else if (rnd > choose_diff && rnd <= (choose_diff + choose_clearcoat)) {
+        lobe = LOBE_CLEARCOAT;
+      } else if (rnd > (choose_diff + choose_clearcoat)
+                 && rnd <= (choose_diff + choose_clearcoat + choose_metal)) {
+        lobe = LOBE_METAL;
+      } else if (rnd > (choose_diff + choose_clearcoat + choose_metal)
+                 && rnd <= (choose_diff + choose_clearcoat + choose_metal + choose_glass)) {
+        lobe = LOBE_GLASS;
+      }
+    }
+    if (lobe == LOBE_CLEARCOAT) {
+      const float gloss = m->clearcoat_gloss;
+      alpha_g = (1.f - gloss) * 0.1f + gloss * 0.001f;
+      if (regularize && alpha_g < 0.1f) alpha_g = clampf(2.f * alpha_g, 0.03f, 0.1f);
+    } else if (lobe == LOBE_METAL || lobe == LOBE_GLASS) {
+      constexpr float alpha_min = 0.0001;
+      float aspect = sqrt_f(1.f - 0.9f * m->anisotropic);
+      // the glass lobe clamps roughness, the metal lobe does not (disney_glass.h:118 vs
+      // disney_metal.h:92-96)
+      if (lobe == LOBE_GLASS) roughness = clampf(roughness, 0.01f, 1.f);
+      float roughness_square = roughness * roughness;
+      alphax = sel_max(alpha_min, roughness_square / aspect);
+      alphay = sel_max(alpha_min, roughness_square * aspect);
+      if (regularize) regularize_alpha(alphax, alphay);
+      const float mat_eta = m->eta;
+      eta = ng_in >= 0 ? mat_eta : 1.f / mat_eta;
+    }
   }
-  const f3 H = normalize(xform_with_onb(frame, local_h));
-  f3 reflected = normalize(-dir_in + 2 * dot(dir_in, H) * H);
-  if (dot(hit.ng, reflected) <= 0) return no_scatter();
-  return Scatter{reflected, 0.f, true, true};
-}
-// sample_disney_metal: disney_metal.h:78-120 (roughness is NOT clamped here, unlike eval_pdf)
-VD Scatter sample_disney_metal(f3 dir_in, const Hit& hit, float roughness, float anisotropic,
-                               const Onb& frame, Rng& rng, bool regularize) {
-  if (dot(hit.ng, dir_in) < 0) return no_scatter();
-  f3 local_dir_in = project_onto_onb(frame, dir_in);
-  constexpr float alpha_min = 0.0001;
-  float aspect = sqrt_f(1.f - 0.9f * anisotropic);
-  float roughness_square = roughness * roughness;
-  float alphax = sel_max(alpha_min, roughness_square / aspect);
-  float alphay = sel_max(alpha_min, roughness_square * aspect);
-  if (regularize) regularize_alpha(alphax, alphay);
-  f3 local_micro_normal = sample_visible_normals(local_dir_in, alphax, alphay, rng);
-  f3 half_vector = normalize(xform_with_onb(frame, local_micro_normal));
-  f3 reflected = normalize(-dir_in + 2 * dot(dir_in, half_vector) * half_vector);
-  if (dot(reflected, hit.ng) <= 0) return no_scatter();
-  return Scatter{reflected, 0.f, true, true};
-}
-// sample_disney_rough_glass: disney_glass.h:108-186
-VD Scatter sample_disney_rough_glass(f3 dir_in, const Hit& hit, float mat_eta, float anisotropic,
-                                     float roughness, const Onb& frame, Rng& rng,
-                                     bool regularize) {
-  float in_geo_dot = dot(dir_in, hit.ng);
-  float eta = in_geo_dot >= 0 ? mat_eta : 1.f / mat_eta;
-  constexpr float alpha_min = 0.0001;
-  float aspect = sqrt_f(1.f - 0.9f * anisotropic);
-  roughness = clampf(roughness, 0.01f, 1.f);
-  float roughness_square = roughness * roughness;
-  float alphax = sel_max(alpha_min, roughness_square / aspect);
-  float alphay = sel_max(alpha_min, roughness_square * aspect);
-  if (regularize) regularize_alpha(alphax, alphay);
-  f3 local_dir_in = project_onto_onb(frame, dir_in);
-  f3 local_micro_normal = sample_visible_normals(local_dir_in, alphax, alphay, rng);
-  f3 half_vec = xform_with_onb(frame, local_micro_normal);
+  if (lobe == LOBE_DIELECTRIC) return dielectric_sample(m, hit, wi, rng);
+  if (lobe == LOBE_NONE) return no_scatter();
+
+  // ---- stage B: the two draws and the azimuth every continuous lobe needs
+  const float ra = rand_float(rng);
+  const float rb = rand_float(rng);
+  const float phi = 2 * kPi * ((lobe == LOBE_CLEARCOAT) ? rb : ra);
+  double sin_phi, cos_phi;
+  sincos_azimuth(phi, sin_phi, cos_phi);
+
+  // ---- stage C: lobe tails
+  if (lobe == LOBE_COSINE) {
+    // sample_hemisphere_cosine (include/rng/sampling.h:69-79): std::cos/std::sin of a float
+    float cos_theta = sqrt_f(rb);
+    float sin_theta = sqrt_f(1 - cos_theta * cos_theta);
+    f3 local{static_cast<float>(cos_phi) * sin_theta, static_cast<float>(sin_phi) * sin_theta,
+             cos_theta};
+    f3 dir = xform_with_onb(frame, local);
+    if (type == VIMG_MAT_LAMBERTIAN) {
+      if (lambert_front) return Scatter{dir, 0.f, false, true};
+      return no_scatter();
+    }
+    if (dot(hit.ng, dir) <= 0) return no_scatter();
+    return Scatter{dir, 0.f, false, true};
+  }
+  if (lobe == LOBE_CLEARCOAT) {
+    const float alpha = alpha_g;
+    float cos2 = (1.f - ::pow(static_cast<double>(alpha * alpha), 1. - ra)) / (1.f - (alpha * alpha));
+    float cos_elevation = sqrt_f(cos2);
+    float sin_elevation = sqrt_f(1 - cos2);
+    f3 local_h{sin_elevation * static_cast<float>(cos_phi), sin_elevation * static_cast<float>(sin_phi),
+               cos_elevation};
+    if (dot(frame.w, dir_in) < 0) {
+      frame.u = -frame.u;
+      frame.v = -frame.v;
+      frame.w = -frame.w;
+    }
+    const f3 H = normalize(xform_with_onb(frame, local_h));
+    f3 reflected = normalize(-dir_in + 2 * dot(dir_in, H) * H);
+    if (dot(hit.ng, reflected) <= 0) return no_scatter();
+    return Scatter{reflected, 0.f, true, true};
+  }
+  // visible-normal sampling shared by the metal and the glass lobe (spherical caps):
+  // unqualified cos/sin there -> double products, narrowed once
+  const f3 local_dir_in = project_onto_onb(frame, dir_in);
+  f3 micro;
+  {
+    float sign = 1.f;
+    f3 top = local_dir_in;
+    if (local_dir_in.z < 0.f) {
+      sign = -1.f;
+      top = -top;
+    }
+    f3 hemi_dir_in = normalize(f3{alphax * top.x, alphay * top.y, top.z});
+    float z = __builtin_fmaf((1.0f - rb), (1.0f + hemi_dir_in.z), -hemi_dir_in.z);
+    float sin_theta = sqrt_f(clampf(1.0f - z * z, 0.0f, 1.0f));
+    float x = sin_theta * cos_phi;
+    float y = sin_theta * sin_phi;
+    const f3 hemi_n = f3{x, y, z} + hemi_dir_in;
+    micro = sign * normalize(f3{alphax * hemi_n.x, alphay * hemi_n.y, sel_max(0.f, hemi_n.z)});
+  }
+  if (lobe == LOBE_METAL) {
+    f3 half_vector = normalize(xform_with_onb(frame, micro));
+    f3 reflected = normalize(-dir_in + 2 * dot(dir_in, half_vector) * half_vector);
+    if (dot(reflected, hit.ng) <= 0) return no_scatter();
+    return Scatter{reflected, 0.f, true, true};
+  }
+  // LOBE_GLASS
+  f3 half_vec = xform_with_onb(frame, micro);
   float h_dot_in = dot(half_vec, dir_in);
   float F = fresnel_dielectric(h_dot_in, eta);
   float rnd = rand_float(rng);
@@ -1082,52 +1234,6 @@ VD Scatter sample_disney_rough_glass(f3 dir_in, const Hit& hit, float mat_eta, f
   float g_h_dot_in = dot(generalized_h, dir_in);
   if ((1 - (1 - g_h_dot_in * g_h_dot_in) / (eta * eta)) <= 0) return no_scatter();
   return Scatter{refracted, eta, true, true};
-}
-// Principled::sample_mat: reference src/material/principled.cpp:3-58
-template <bool TEX>
-VD Scatter principled_sample(const DScene& g, gptr<VimgMaterial> m, f3 wi,
-                                                  const Hit& hit, Rng& rng, bool regularize) {
-  const PrincipledCommon pc = principled_prologue<TEX>(g, m, wi, hit);
-  const f3 dir_in = pc.dir_in;
-  const float metallic = pc.metallic, roughness = pc.roughness;
-  if (dot(hit.ng, dir_in) < 0)
-    return sample_disney_rough_glass(dir_in, hit, m->eta, m->anisotropic, roughness, pc.frame, rng,
-                                     regularize);
-  const float st = m->specular_transmission;
-  float diffuse_weight = (1.f - metallic) * (1.f - st);
-  float clearcoat_weight = 0.25f * m->clearcoat;
-  float metal_weight = (1.f - st * (1.f - metallic));
-  float glass_weight = (1.f - metallic) * st;
-  float total_w = diffuse_weight + clearcoat_weight + metal_weight + glass_weight;
-  float choose_diff = diffuse_weight / total_w;
-  float choose_clearcoat = clearcoat_weight / total_w;
-  float choose_metal = metal_weight / total_w;
-  float choose_glass = glass_weight / total_w;
-  float rnd = rand_float(rng);
-  if (rnd <= choose_diff) {
-    return sample_disney_diffuse(dir_in, hit, pc.frame, rng);
-  } else if (rnd > choose_diff && rnd <= (choose_diff + choose_clearcoat)) {
-    return sample_disney_clearcoat(dir_in, hit, pc.frame, m->clearcoat_gloss, rng, regularize);
-  } else if (rnd > (choose_diff + choose_clearcoat)
-             && rnd <= (choose_diff + choose_clearcoat + choose_metal)) {
-    return sample_disney_metal(dir_in, hit, roughness, m->anisotropic, pc.frame, rng, regularize);
-  } else if (rnd > (choose_diff + choose_clearcoat + choose_metal)
-             && rnd <= (choose_diff + choose_clearcoat + choose_metal + choose_glass)) {
-    return sample_disney_rough_glass(dir_in, hit, m->eta, m->anisotropic, roughness, pc.frame, rng,
-                                     regularize);
-  }
-  return no_scatter();
-}
-
-// Material::sample_mat dispatch (virtual in the reference, include/material/material.h:37-40)
-template <bool TEX>
-VD Scatter sample_mat(const DScene& g, const Hit& hit, f3 wi, Rng& rng, bool regularize) {
-  gptr<VimgMaterial> m = g.materials + hit.mat;
-  const uint32_t type = m->type;
-  if (type == VIMG_MAT_LAMBERTIAN) return lambertian_sample(hit, wi, rng);
-  if (type == VIMG_MAT_PRINCIPLED) return principled_sample<TEX>(g, m, wi, hit, rng, regularize);
-  if (type == VIMG_MAT_DIELECTRIC) return dielectric_sample(m, hit, wi, rng);
-  return no_scatter();   // DiffuseLight: base class returns nullopt
 }
 // Material::eval_pdf_pair dispatch; the base class returns (0, 1) (material.h:56-60), which is
 // what Dielectric and DiffuseLight inherit
@@ -1395,7 +1501,7 @@ VD Lds stage_lds(const DScene& g, const RenderArgs& A, VIMG_LDS unsigned char* l
     na[i] = src->a;
     nb[i] = src->b;
     nc[i] = src->c;
-    nm[i] = v2u{src->first_index, src->obj_count};
+    nm[i] = v2u{src->left_ref, src->right_ref};
   }
   __syncthreads();
   // stacks start at the next 256-byte boundary: [wave][entry][lane]
@@ -1426,8 +1532,8 @@ render_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
   const uint32_t total_items = single ? 1u : A.num_local_tiles * 64u;
   constexpr uint32_t roulette_threshold = 5;
 
-  Counters cnt{0, 0, 0, 0, 0, 0};
-  uint32_t nan_samples = 0;
+  Counters cnt{0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t nan_samples = 0, iter_wave = 0;
 
   // per-pixel state
   bool alive = true, need_pixel = true;
@@ -1486,6 +1592,7 @@ render_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
     }
     if (!__any(alive)) break;
     const bool active = alive && !need_pixel;
+    if (full_stats && lane == 0) iter_wave++;
 
     // ------------------------------------------------------------------ camera ray
     if (active && new_path) {
@@ -1720,7 +1827,8 @@ render_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
     unsigned long long c0 = wave_sum(cnt.closest), c1 = wave_sum(cnt.shadow),
                        c2 = wave_sum(cnt.internal), c3 = wave_sum(cnt.leaf),
                        c4 = wave_sum(cnt.prim), c5 = wave_sum(nan_samples),
-                       c6 = wave_sum(cnt.sphere);
+                       c6 = wave_sum(cnt.sphere), c7 = wave_sum(cnt.trip_descend),
+                       c8 = wave_sum(cnt.trip_prim), c9 = wave_sum(iter_wave);
     if (lane == 0) {
       atomicAdd(&stats->closest, c0);
       atomicAdd(&stats->shadow, c1);
@@ -1729,6 +1837,9 @@ render_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
         atomicAdd(&stats->leaf, c3);
         atomicAdd(&stats->prim, c4);
         atomicAdd(&stats->sphere, c6);
+        atomicAdd(&stats->trip_descend, c7);
+        atomicAdd(&stats->trip_prim, c8);
+        atomicAdd(&stats->iterations, c9);
       }
       if (c5) atomicAdd(&stats->nan_samples, c5);
     }
@@ -1768,7 +1879,7 @@ probe_kernel(const DScene g, const RenderArgs A, int kind, int n, const float* _
   const Lds L = stage_lds(g, A, (VIMG_LDS unsigned char*)lds_raw);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Counters cnt{0, 0, 0, 0, 0, 0};
+  Counters cnt{0, 0, 0, 0, 0, 0, 0, 0};
   auto trace = [&](const float* p, Hit& h, TravRay& tr) {
     tr = TravRay{f3{p[0], p[1], p[2]}, f3{p[3], p[4], p[5]}, 0.0001f, VIMG_INF};
     HitRec rec;

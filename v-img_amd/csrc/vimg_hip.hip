@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numbers>
 #include <string>
@@ -295,6 +296,10 @@ int fetch_stats(VimgDeviceScene* s, const VimgRenderParams* p, VimgRenderStats* 
     px += uint64_t(std::min(8u, W - tx * 8)) * std::min(8u, H - ty * 8);
   }
   out->paths = px * p->samples;
+  if (getenv("VIMG_HIP_DIAG"))
+    std::fprintf(stderr, "[vimg diag] wave trips: descend %llu (lane visits %llu, util %.3f)  prim %llu (lane tests %llu, util %.3f)  main-loop iterations %llu\n",
+                 ds.trip_descend, ds.internal, ds.trip_descend ? double(ds.internal) / (64.0 * ds.trip_descend) : 0.0,
+                 ds.trip_prim, ds.prim, ds.trip_prim ? double(ds.prim) / (64.0 * ds.trip_prim) : 0.0, ds.iterations);
   return VIMG_OK;
 }
 
@@ -357,39 +362,53 @@ int vimg_hip_scene_upload(const VimgScene* sc, VimgDeviceScene** out) {
   d.res_x = cam.res_x;
   d.res_y = cam.res_y;
 
-  // ---- BVH: breadth-first renumbering (sibling pairs stay adjacent, root stays 0) so that the
-  // lowest indices are the top of the tree — the part staged into LDS.  Traversal order depends
-  // on the tree, not on the numbering, so results are unchanged.
+  // ---- BVH: only internal nodes get a record; they are renumbered breadth-first (root = 0) so
+  // that the lowest indices are the top of the tree — the part staged into LDS.  Traversal order
+  // depends on the tree, not on the numbering, so results are unchanged.
   const VimgBVH& b = sc->bvh;
-  std::vector<uint32_t> order;   // new index -> old index
-  order.reserve(b.num_nodes);
-  order.push_back(0);
+  auto pack_leaf = [&](const VimgBVHNode& n, uint32_t& out) {
+    if (n.obj_count > 127 || n.first_index >= (1u << 25)) return false;
+    out = (n.obj_count << 25) | n.first_index;
+    return true;
+  };
+  std::vector<uint32_t> order;   // internal nodes: new index -> old index
   std::vector<uint32_t> new_of(b.num_nodes, 0);
+  if (b.nodes[0].obj_count == 0) order.push_back(0);
   for (size_t head = 0; head < order.size(); ++head) {
     const VimgBVHNode& n = b.nodes[order[head]];
-    if (n.obj_count == 0) {
-      new_of[n.first_index] = static_cast<uint32_t>(order.size());
-      order.push_back(n.first_index);
-      new_of[n.first_index + 1] = static_cast<uint32_t>(order.size());
-      order.push_back(n.first_index + 1);
-    }
+    for (uint32_t c = n.first_index; c <= n.first_index + 1; ++c)
+      if (b.nodes[c].obj_count == 0) {
+        new_of[c] = static_cast<uint32_t>(order.size());
+        order.push_back(c);
+      }
   }
+  if (order.size() >= (1u << 25)) return bail(fail(VIMG_E_UNSUPPORTED, "BVH has more than 2^25 internal nodes"));
   std::vector<DNode> nodes(order.size());
   for (size_t i = 0; i < order.size(); ++i) {
     const VimgBVHNode& n = b.nodes[order[i]];
     DNode dn{};
-    dn.obj_count = n.obj_count;
-    if (n.obj_count != 0) {
-      dn.first_index = n.first_index;
-    } else {
-      dn.first_index = new_of[n.first_index];
-      const float* bb = b.bb_mins_maxes + (size_t(n.first_index) * 2 + 2) * 3;
-      const float* lmin = bb, *rmin = bb + 3, *lmax = bb + 6, *rmax = bb + 9;
-      dn.a = v4f{lmin[0], lmin[1], lmin[2], lmax[0]};
-      dn.b = v4f{lmax[1], lmax[2], rmin[0], rmin[1]};
-      dn.c = v4f{rmin[2], rmax[0], rmax[1], rmax[2]};
+    uint32_t refs[2];
+    for (int k = 0; k < 2; ++k) {
+      const uint32_t c = n.first_index + k;
+      if (b.nodes[c].obj_count == 0) {
+        refs[k] = new_of[c];
+      } else if (!pack_leaf(b.nodes[c], refs[k])) {
+        return bail(fail(VIMG_E_UNSUPPORTED, "BVH leaf with more than 127 primitives or more than 2^25 primitives"));
+      }
     }
+    dn.left_ref = refs[0];
+    dn.right_ref = refs[1];
+    const float* bb = b.bb_mins_maxes + (size_t(n.first_index) * 2 + 2) * 3;
+    const float* lmin = bb, *rmin = bb + 3, *lmax = bb + 6, *rmax = bb + 9;
+    dn.a = v4f{lmin[0], lmin[1], lmin[2], lmax[0]};
+    dn.b = v4f{lmax[1], lmax[2], rmin[0], rmin[1]};
+    dn.c = v4f{rmin[2], rmax[0], rmax[1], rmax[2]};
     nodes[i] = dn;
+  }
+  if (b.nodes[0].obj_count == 0) {
+    d.root_ref = 0;
+  } else if (!pack_leaf(b.nodes[0], d.root_ref)) {
+    return bail(fail(VIMG_E_UNSUPPORTED, "single-leaf BVH with more than 127 primitives"));
   }
   for (int a = 0; a < 3; ++a) {
     d.root_min[a] = b.bb_mins_maxes[0 * 3 + a];
