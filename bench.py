@@ -119,7 +119,7 @@ def main():
     else:
         stride = vdist.shard_stride_pixels(W, H, n)
         slab = torch.zeros((stride, 3), dtype=torch.float32, device="cuda")
-        gathered = torch.empty((n, stride, 3), dtype=torch.float32, device="cuda")
+        gathered = torch.empty((n * stride, 3), dtype=torch.float32, device="cuda")
         frame = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
 
     def step(ev=None):

@@ -1,0 +1,280 @@
+"""Pins of the CPU oracle (oracle/liboracle.so) — what makes it trustworthy as the checker.
+
+Sources of the expected values:
+  [REF]    fixtures the reference itself holds: scenes/MIS_light_tests/*_mis.json with their
+           converged *-ref.png images (copied as data under tests/golden/scenes), and the
+           analytic radiance of those scenes;
+  [PCG]    the canonical PCG32 demo vector (pcg_rand.h is the published pcg32 algorithm);
+  [SURVEY] values SURVEY.md Appendix B recorded from the reference's own code in the survey
+           container (g++ -O3 -march=native, i.e. WITH fused multiply-add contraction).  The
+           oracle is built -ffp-contract=off (ISO semantics, reproducible on the GPU), so values
+           that go through a contracted `a*n - floor(a*n)` (the R2 jitter) differ by up to
+           ulp(a*n); the tolerances below say so.
+The reference cannot be compiled in this image (glm / fastgltf / nlohmann 3.11 absent) and has
+no tests of its own; see DESIGN.md "Oracle".
+"""
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import oracle_lib as O
+import scenes
+import vimg_amd
+from vimg_amd import abi
+
+
+def f32(x):
+    return float(np.float32(x))
+
+
+# ------------------------------------------------------------------------------- integer RNG
+def test_pcg32_canonical_demo_vector():   # [PCG] seed 42, seq 54
+    p = O.Pcg(42, 54)
+    assert [p.u32() for _ in range(6)] == [0xa15c02b7, 0x7b47f409, 0xba1d3330, 0x83d2f293,
+                                           0xbfa4784b, 0xcbed606e]
+
+
+@pytest.mark.parametrize("seed,state,u32s,floats", [   # [SURVEY] Appendix B
+    (0, 0x5851f42d4c957f2e, [0xe4c14788, 0x379c6516, 0x5c4ab3bb, 0x601d23e0],
+     [0.610917449, 0.30691433, 0.122396633]),
+    (1, 0xb0a3e85a992afe5b, [0xe2393051, 0x01112f35, 0xd3509d35, 0x0b932f4a],
+     [0.567126572, 0.574940324, 0.82471025]),
+    (12345, 0x6059d09f61b74033, [0x1220b391, 0x98d38aaa, 0x5bbddfa6, 0x871ffa62],
+     [0.103291824, 0.312457144, 0.0976030976]),
+])
+def test_pcg32_pixel_seeding_and_rand_float(seed, state, u32s, floats):
+    p = O.Pcg(seed, 0)
+    assert p.state == state and p.inc == 1
+    assert [p.u32() for _ in range(4)] == u32s
+    p = O.Pcg(seed, 0)
+    assert [f32(p.rand_float()) for _ in range(3)] == [f32(v) for v in floats]
+
+
+def test_rand_float_is_dense_and_in_unit_interval():
+    p = O.Pcg(99, 0)
+    v = np.array([p.rand_float() for _ in range(20000)], dtype=np.float32)
+    assert v.min() >= 0 and v.max() < 1
+    assert abs(v.mean() - 0.5) < 0.01
+    # dense floats: values below 2^-3 keep 24 significant bits (not multiples of 2^-24)
+    small = v[v < 0.125]
+    assert np.any(np.mod(small.astype(np.float64) * 2 ** 24, 1.0) != 0)
+
+
+def test_r2_sequence():   # [SURVEY]; n >= 3 went through an FMA there, see module docstring
+    assert [f32(v) for v in O.r2(1)] == [f32(0.245122358), f32(0.430159748)]
+    assert [f32(v) for v in O.r2(2)] == [f32(0.490244716), f32(0.860319495)]
+    for n, ref in [(3, (0.73536706, 0.290479243)), (1300, (0.659065664, 0.207671881))]:
+        got = O.r2(n)
+        tol = n * 0.57 * 2 ** -23          # one ulp of a1*n
+        assert abs(got[0] - ref[0]) <= tol and abs(got[1] - ref[1]) <= tol
+
+
+# ------------------------------------------------------------------------------- camera / hits
+def test_disney_camera_rays():   # [SURVEY]
+    s = scenes.json_scene("disney_spheres.json")
+    for (x, y, d_ref) in [(0, 0, (-0.437831104, -0.207734436, -0.874728799)),
+                          (900, 400, (0.00036528206, -0.0148832295, -0.999889195)),
+                          (1799, 799, (0.4377819, 0.181202874, -0.880631983))]:
+        off = O.r2(x + y)
+        r = O.probe(s, O.PROBE_CAMERA_RAY,
+                    [[np.float32(x) + np.float32(off[0]), np.float32(y) + np.float32(off[1]),
+                      0.5, 0.5]])[0]
+        assert np.array_equal(r[:3], np.float32([0, 20, 1600]))
+        assert np.allclose(r[3:6], d_ref, atol=2e-8 + 1e-7 * 0)   # jitter differs by <= 1e-4 px
+        assert r[6] == 0 and f32(r[7]) == f32(0.000554236583)     # primary ray cone
+
+
+def test_thin_lens_ray():   # [SURVEY] aperture 5, fdist 1600, px (900.5, 400.5), rand1 .25, rand2 .75
+    s = vimg_amd.HostScene()
+    s.set_camera((0, 20, 1600), (0, -4, 0), (0, 1, 0), 25.0, (1800, 800), aperture_radius=5.0,
+                 focal_dist=1600.0)
+    t = s.add_texture_const((0.5, 0.5, 0.5))
+    m = s.add_material("lambertian", tex=t)
+    s.add_sphere((0, 0, 0), 1.0, m)
+    s.build_bvh()
+    r = O.probe(s, O.PROBE_CAMERA_RAY, [[900.5, 400.5, 0.25, 0.75]])[0]
+    assert np.allclose(r[:3], (2.98122025e-08, 17.5002804, 1600.03748), rtol=1e-7, atol=1e-7)
+    # components of a unit vector: absolute agreement to a tenth of an ulp of 1 (the survey build
+    # contracted multiply-adds)
+    assert np.allclose(r[3:6], (0.000277097715, -0.0131588709, -0.999913394), rtol=0, atol=1e-8)
+
+
+def test_sphere_intersection_distance():   # [SURVEY] Sphere((100,-177.5,40),100)
+    s = scenes.json_scene("disney_spheres.json")
+    d = np.array([0.06, -0.12, -1.0], dtype=np.float32)
+    d = d * (np.float32(1) / np.sqrt(np.float32(d @ d)))
+    h = O.probe(s, O.PROBE_CLOSEST_HIT, [[0, 20, 1600, *d]])[0]
+    assert h[0] == 1 and h[2] == 15            # prim 15 = sphere d_4
+    assert abs(h[1] - 1476.30798) < 2e-3
+
+
+def test_sweep_bvh_node_lists():   # [SURVEY] Appendix B: exact node and index lists
+    s = scenes.json_scene("disney_spheres.json")
+    nodes, bb, obj, depth = s.bvh_arrays()
+    assert depth == 6 and len(nodes) == 23 and bb.shape == (49, 3)
+    assert [tuple(int(v) for v in n) for n in nodes] == [
+        (1, 0), (3, 0), (15, 0), (5, 0), (9, 0), (0, 1), (7, 0), (1, 1), (2, 1), (11, 0), (3, 2),
+        (5, 1), (13, 0), (6, 1), (7, 1), (17, 0), (19, 0), (16, 2), (14, 2), (8, 2), (21, 0),
+        (12, 2), (10, 2)]
+    assert obj.tolist() == [12, 13, 14, 4, 5, 15, 16, 17, 6, 7, 1, 0, 9, 8, 2, 3, 10, 11]
+    s = scenes.json_scene("glass_in_box.json")
+    nodes, _, obj, depth = s.bvh_arrays()
+    assert depth == 6
+    assert [tuple(int(v) for v in n) for n in nodes] == [
+        (1, 0), (3, 0), (5, 0), (11, 2), (9, 2), (0, 2), (7, 0), (2, 2), (9, 0), (7, 2), (11, 0),
+        (6, 1), (4, 2)]
+    assert obj.tolist() == [0, 1, 6, 7, 4, 5, 12, 8, 9, 2, 3, 10, 11]
+    # binned builder: same 23-node topology with nodes 17/18 swapped
+    s = scenes.json_scene("disney_spheres.json", bvh=abi.BVH_BINNED)
+    nodes, _, _, depth = s.bvh_arrays()
+    assert depth == 6 and len(nodes) == 23
+    assert tuple(nodes[17]) == (14, 2) and tuple(nodes[18]) == (16, 2)
+
+
+# ------------------------------------------------------------------------------- whole scenes
+def test_config1_glass_in_box_normal_integrator():   # BASELINE config 1 [SURVEY]
+    s = scenes.json_scene("glass_in_box.json")
+    img, st, _ = O.render(s, s.default_params(integrator="s_normal", samples=64))
+    assert st.rays == st.paths == 640 * 480 * 64 and st.shadow_rays == 0
+    # survey (AVX2 build, ~1e-4 of rays falsely miss a box there): 0.499380 0.490777 0.634283
+    assert np.allclose(img.reshape(-1, 3).mean(0), (0.499380, 0.490777, 0.634283), atol=1e-4)
+    assert abs(st.internal_visits / st.rays - 4.59) < 0.01
+    assert abs(st.leaf_visits / st.rays - 1.09) < 0.01
+
+
+def _analytic_floor_radiance(s, radius, emit, light_pos):
+    """rho * Le * r^2 * cos(theta) / d^2 for every pixel whose centre ray hits the floor (z=0)."""
+    w, h = s.resolution
+    xs, ys = np.meshgrid(np.arange(w, dtype=np.float32) + 0.5, np.arange(h, dtype=np.float32) + 0.5)
+    cam = np.stack([xs.ravel(), ys.ravel(), np.zeros(w * h, np.float32), np.zeros(w * h, np.float32)], 1)
+    rays = O.probe(s, O.PROBE_CAMERA_RAY, cam)[:, :6]
+    hits = O.probe(s, O.PROBE_CLOSEST_HIT, rays)
+    floor = (hits[:, 0] == 1) & (hits[:, 3] == 1)           # material 1 = the white floor quad
+    p = hits[:, 4:7].astype(np.float64)
+    to_l = np.asarray(light_pos, dtype=np.float64) - p
+    d2 = (to_l ** 2).sum(1)
+    cos_t = to_l[:, 2] / np.sqrt(d2)
+    expected = 1.0 * emit * radius ** 2 * cos_t / d2
+    # image row 0 = top: pixel (x, y) lives at [h-1-y, x]
+    exp_img = np.zeros((h, w))
+    mask = np.zeros((h, w), dtype=bool)
+    yi = (h - 1 - np.floor(ys.ravel())).astype(int)
+    xi = np.floor(xs.ravel()).astype(int)
+    exp_img[yi, xi] = expected
+    mask[yi, xi] = floor
+    return exp_img, mask
+
+
+@pytest.mark.parametrize("name,radius,emit,mean_tol,png_tol", [
+    ("small", 0.125, 64.0, 0.005, 0.0015),     # reference code itself: +0.11 %
+    ("medium", 0.5, 4.0, 0.03, 0.004),         # reference code itself: +1.6 % (Q16 bias)
+])
+def test_sphere_light_scenes_analytic_and_reference_png(name, radius, emit, mean_tol, png_tol):
+    # [REF] the reference's own known-answer scenes (depth 1, white Lambertian floor)
+    s = scenes.json_scene(f"MIS_light_tests/sphere_light_{name}_mis.json")
+    p = s.default_params()
+    assert (p.samples, p.depth, p.integrator) == (64, 1, abi.INTEGRATOR_MIS)
+    img, st, _ = O.render(s, p)
+    assert st.nan_samples == 0
+    expected, mask = _analytic_floor_radiance(s, radius, emit, (0, 0, 1))
+    # stay clear of the sphere's silhouette and of the far field where noise dominates
+    mask &= expected > 0.02
+    ratio = img[..., 0][mask].mean() / expected[mask].mean()
+    assert abs(ratio - 1) < mean_tol, ratio
+    ref = np.asarray(Image.open(os.path.join(scenes.SCENES, "MIS_light_tests",
+                                             f"sphere_light_{name}-ref.png"))).astype(np.float32) / 255
+    ours = vimg_amd.tonemap_to_rgb8(img, 0).astype(np.float32) / 255     # clamp + sRGB + 8 bit
+    assert np.abs(ours - ref).mean() < png_tol
+
+
+def test_cornell_box_spheres_mean_radiance():   # [SURVEY] 0.16369 0.14589 0.13198, 7.83 rays/path
+    s = scenes.json_scene("cornell_box_spheres.json", res=(400, 400))
+    img, st, _ = O.render(s, s.default_params(samples=32))
+    assert np.allclose(img.reshape(-1, 3).mean(0), (0.16369, 0.14589, 0.13198), rtol=0.012)
+    assert abs(st.rays / st.paths - 7.83) < 0.08
+    assert st.nan_samples == 0
+
+
+def test_config2_disney_spheres_statistics():   # BASELINE config 2 at low spp [SURVEY]
+    s = scenes.json_scene("disney_spheres.json")
+    p = s.default_params(samples=4)
+    assert p.depth == 0xFFFFFFFF and p.integrator == abi.INTEGRATOR_MIS
+    img, st, _ = O.render(s, p)
+    # three builds of the reference itself span 0.9 % in mean radiance
+    assert np.allclose(img.reshape(-1, 3).mean(0), (0.33916, 0.32552, 0.34845), rtol=0.015)
+    assert abs(st.rays / st.paths - 5.7125) < 0.06
+    assert abs(st.internal_visits / st.rays - 6.33) < 0.15
+    assert st.nan_samples == 0
+
+
+def test_glass_in_box_dielectric_goes_black_under_mis():   # [SURVEY] quirk Q1, 10.59 rays/path
+    s = scenes.json_scene("glass_in_box.json", res=(160, 120))
+    img, st, _ = O.render(s, s.default_params(samples=16))
+    assert abs(st.rays / st.paths - 10.59) < 0.2
+    # pixels whose every sample first hits the glass sphere are exactly black: Dielectric has no
+    # eval_pdf_pair, the base class returns (0, 1) and the throughput becomes 0
+    xs, ys = np.meshgrid(np.arange(160, dtype=np.float32) + 0.5, np.arange(120, dtype=np.float32) + 0.5)
+    cam = np.stack([xs.ravel(), ys.ravel(), 0 * xs.ravel(), 0 * xs.ravel()], 1)
+    hits = O.probe(s, O.PROBE_CLOSEST_HIT, O.probe(s, O.PROBE_CAMERA_RAY, cam)[:, :6])
+    glass = ((hits[:, 0] == 1) & (hits[:, 3] == 4)).reshape(120, 160)     # material 4 = "glass"
+    assert glass.sum() > 100
+    # interior of the silhouette (all 8 neighbours are glass too)
+    inner = glass.copy()
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            inner &= np.roll(np.roll(glass, dy, 0), dx, 1)
+    assert inner.sum() > 50
+    assert np.all(img[::-1][inner] == 0)
+
+
+# ------------------------------------------------------------------------------- self-consistency
+def test_trace_pixel_equals_render_and_threads_do_not_matter():
+    s = scenes.json_scene("disney_spheres.json", res=(90, 40))
+    p = s.default_params(samples=8)
+    a, _, _ = O.render(s, p, threads=1)
+    b, _, used = O.render(s, p, threads=8)
+    assert used == 8 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for (x, y) in [(0, 0), (45, 20), (89, 39)]:
+        assert np.array_equal(O.trace_pixel(s, p, x, y), a[40 - 1 - y, x])
+
+
+def test_tile_shards_cover_the_image_exactly():
+    s = scenes.json_scene("disney_spheres.json", res=(61, 37))
+    p = s.default_params(samples=2)
+    full, st, _ = O.render(s, p)
+    acc = np.zeros_like(full)
+    paths = 0
+    for r in range(3):
+        part, pst, _ = O.render(s, s.default_params(samples=2, tile_rank=r, tile_world=3))
+        assert np.all((part == 0) | (acc == 0))       # disjoint
+        acc += part
+        paths += pst.paths
+    assert paths == st.paths and np.array_equal(acc, full)
+
+
+def test_float_libm_build_agrees_with_default_build():
+    """The default oracle evaluates float transcendentals as (float)fn((double)x) so that the GPU
+    can reproduce it; the -DORACLE_LIBM_FLOAT build makes the reference's literal cosf/acosf/...
+    calls.  Both are faithfully rounded: unit values agree to 1 ulp, images statistically."""
+    import subprocess
+    subprocess.run(["make", "-C", O.ROOT, "oracle/liboracle_libmf.so"], check=True,
+                   capture_output=True)
+    lf = O.load("liboracle_libmf.so")
+    assert lf.oracle_uses_float_libm() == 1 and O.load().oracle_uses_float_libm() == 0
+    s = scenes.feature_scene(res=(64, 48))
+    rng = np.random.default_rng(5)
+    cam = np.stack([rng.uniform(0, 64, 512), rng.uniform(0, 48, 512), rng.random(512),
+                    rng.random(512)], 1).astype(np.float32)
+    a, b = O.probe(s, O.PROBE_CAMERA_RAY, cam), O.probe(s, O.PROBE_CAMERA_RAY, cam, lib=lf)
+    assert np.allclose(a, b, rtol=3e-7, atol=1e-7)
+    ha, hb = O.probe(s, O.PROBE_CLOSEST_HIT, a[:, :6]), O.probe(s, O.PROBE_CLOSEST_HIT, a[:, :6], lib=lf)
+    assert np.array_equal(ha[:, :4], hb[:, :4])
+    assert np.allclose(ha, hb, rtol=1e-5, atol=1e-6)
+    p = s.default_params(samples=16, depth=8)
+    ia, _, _ = O.render(s, p)
+    ib, _, _ = O.render(s, p, lib=lf)
+    assert abs(ia.mean() - ib.mean()) < 0.02 * ia.mean()
+    same = (ia.view(np.uint32) == ib.view(np.uint32)).all(-1).mean()
+    assert same > 0.5     # most pixels are not touched by a 1-ulp difference at all

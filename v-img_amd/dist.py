@@ -58,7 +58,25 @@ def render_sharded(dev_scene, params_fn, rank, world, group=None):
     stride = shard_stride_pixels(w, h, world)
     slab = torch.zeros((stride, 3), dtype=torch.float32, device="cuda")
     _, stats = dev_scene.render(params, out=slab)
-    gathered = torch.empty((world, stride, 3), dtype=torch.float32, device="cuda")
+    # concatenated layout [world * stride, 3]: accepted by both RCCL and gloo
+    gathered = torch.empty((world * stride, 3), dtype=torch.float32, device="cuda")
     dist.all_gather_into_tensor(gathered, slab, group=group)
     image = dev_scene.assemble_shards(gathered, world, stride)
     return image, stats
+
+
+def extract_shard(image, rank, world):
+    """Inverse of assemble: cut the compact [stride, 3] slab of `rank` out of a full [H, W, 3]
+    image (pixels outside the image stay 0).  Host helper for tests and CPU-side plumbing."""
+    height, width = image.shape[0], image.shape[1]
+    tx, ty = tile_grid(width, height)
+    stride = shard_stride_pixels(width, height, world)
+    slab = np.zeros((stride, 3), dtype=image.dtype)
+    for local, t in enumerate(shard_tiles(width, height, rank, world)):
+        x0, y0 = (t // ty) * 8, (t % ty) * 8
+        h, w = min(8, height - y0), min(8, width - x0)
+        block = np.zeros((8, 8, 3), dtype=image.dtype)
+        for yy in range(h):
+            block[yy, :w] = image[height - 1 - (y0 + yy), x0:x0 + w]
+        slab[local * 64:(local + 1) * 64] = block.reshape(64, 3)
+    return slab
