@@ -80,6 +80,12 @@ def main():
     ap.add_argument("--strong", action="store_true", help="keep 1800x800 total (strong scaling)")
     ap.add_argument("--cpu-spp", type=int, default=16, help="samples of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N>1 path (host-staged gather), not a measurement")
+    ap.add_argument("--verify", action="store_true",
+                    help="N>1: rank 0 also renders the whole frame alone and compares bit for bit")
+    ap.add_argument("--one-device", action="store_true",
+                    help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -94,10 +100,14 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run "
                              "(one rank per GPU)")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    hip.init(local_rank)
+    dev_index = 0 if args.one_device else local_rank
+    torch.cuda.set_device(dev_index)
+    hip.init(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
 
     n = world
     if args.strong or n == 1:
@@ -129,14 +139,20 @@ def main():
         if ev is not None:
             ev[1].record(stream)
         if n > 1:
-            dist.all_gather_into_tensor(gathered, slab)
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(gathered, slab)     # RCCL over xGMI, once per frame
+            else:
+                host = torch.empty(gathered.shape, dtype=torch.float32)
+                dist.all_gather_into_tensor(host, slab.cpu())
+                gathered.copy_(host)
             dev.assemble_shards(gathered, n, stride, out=frame, stream=stream)
 
     # event counts of one step (deterministic: same seeds every step); not timed
     _, st = dev.render(params, out=slab, stats=True, stream=stream)
     local_pixels = st.paths // args.spp
+    red_dev = "cuda" if args.backend == "nccl" else "cpu"
     counts = torch.tensor([st.rays, st.paths, algorithmic_bytes(st, local_pixels)],
-                          dtype=torch.float64, device="cuda")
+                          dtype=torch.float64, device=red_dev)
     if n > 1:
         dist.all_reduce(counts)
     total_rays, total_paths = float(counts[0]), float(counts[1])
@@ -156,12 +172,17 @@ def main():
     if n > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if n > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t[0])
     kernel_ms = sum(a.elapsed_time(b) for a, b in events) / args.steps
 
+    if args.verify and n > 1 and rank == 0:
+        alone, _ = dev.render(scene.default_params(samples=args.spp), stream=stream)
+        torch.cuda.synchronize()
+        assert torch.equal(alone, frame), "assembled shards differ from the single-GPU frame"
+        print("verify: assembled frame is bit-identical to the single-GPU frame", file=sys.stderr)
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_rays * args.steps / elapsed / 1e6

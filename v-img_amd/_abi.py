@@ -202,7 +202,8 @@ def hip_lib():
     """The HIP extension.  No CPU fallback exists: a missing library raises."""
     global _hip_lib
     if _hip_lib is None:
-        path = os.path.join(LIB_DIR, "libvimg_hip.so")
+        # VIMG_HIP_LIB selects another build of the same library (A/B measurements only)
+        path = os.environ.get("VIMG_HIP_LIB") or os.path.join(LIB_DIR, "libvimg_hip.so")
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: run `make hip` (or __graft_entry__.build()); "
                                "there is no CPU fallback for the render path")
