@@ -53,6 +53,32 @@ def load_scene(res):
     return vimg_amd.HostScene.from_json_text(json.dumps(d))
 
 
+def cpu_share():
+    """Host cores this job may use: min(affinity mask, cgroup CPU quota).  The GPU box exposes
+    all hardware threads of the node but gives a one-GPU job a 16-CPU share."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    if n > 64:            # no quota visible: stay within the documented per-GPU share
+        n = 16
+    return n
+
+
+def measured_traffic(workload):
+    """HBM bytes per launch from the committed rocprofv3 PMC pass of this same workload."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if t.get("workload") == workload:
+            return int(t["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def cpu_baseline(spp):
     """The CPU port (oracle/) timed on this box's host cores on a bounded sample of the same
     workload: the same 1800x800 pixels, the first `spp` of the 512 samples."""
@@ -61,8 +87,7 @@ def cpu_baseline(spp):
     scene = load_scene((1800, 800))
     params = scene.default_params(samples=spp)
     t0 = time.perf_counter()
-    # the box may expose more hardware threads than this job's CPU share: use the share
-    share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 0
+    share = cpu_share()
     _, st, threads = O.render(scene, params, threads=share)
     dt = time.perf_counter() - t0
     return {"value": round(st.rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": int(threads),
@@ -216,7 +241,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "traffic": measured_traffic(f"disney_spheres.json, mis integrator, {args.spp} spp, {W}x{H}")
+                if n == 1 else None,
                 "kernel": "render_kernel<false>",
                 "bytes_per_launch": int(local_bytes),
                 "note": "algorithmic bytes on the reference layout (SURVEY.md 8d); the 2 KB scene "

@@ -24,5 +24,5 @@ if g("SQ_ACTIVE_INST_VALU"):
     d["wait_any_share"] = g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES")
 print(json.dumps({"dispatch": meta, "counters": agg, "derived": d,
                   "note": "each counter is summed over the render_kernel dispatches of its pass "
-                          "(bench.py --steps 1 --warmup 0 --spp 64: one stats launch + one timed launch)"},
+                          "(bench.py --steps 1 --warmup 0 --spp 512: one stats launch + one timed launch)"},
                  indent=1))
