@@ -20,11 +20,10 @@
 
 namespace vimg {
 
-// Register budget of the render kernel: waves per SIMD the compiler must leave room for
-// (2 -> 256 VGPRs, 3 -> 168, 4 -> 128).  Measured on MI355X (DESIGN.md "Occupancy"): 2 is best.
-#ifndef VIMG_WAVES_PER_SIMD
-#define VIMG_WAVES_PER_SIMD 2
-#endif
+// Register budget of the render kernel = its WPS template argument: waves per SIMD the compiler
+// must leave room for (2 -> 256 VGPRs, 3 -> 168, 4 -> 128).  Measured on MI355X (DESIGN.md
+// "Occupancy"): scenes that live in LDS/L1 are VALU-bound and fastest at 2 (least spilling);
+// scenes of hundreds of MB are latency-bound and fastest at 3.
 
 // ================================================================================ RNG
 // pcg32 with initseq = 0 (inc = 1): reference include/rng/pcg_rand.h:15-33, seeded per pixel by
@@ -1525,8 +1524,8 @@ VD Lds stage_lds(const DScene& g, const RenderArgs& A, VIMG_LDS unsigned char* l
 // scene_integrator + mis_integrator / normal integrators:
 // reference include/integrators.h:36-153, src/integrators/mis_integrator.cpp:18-189,
 // src/integrators/normals.cpp:4-46
-template <bool TEX>
-__global__ void __launch_bounds__(256, VIMG_WAVES_PER_SIMD)
+template <bool TEX, int WPS>
+__global__ void __launch_bounds__(256, WPS)
 render_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
               DeviceStats* __restrict__ stats, unsigned int* __restrict__ work_counter) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];

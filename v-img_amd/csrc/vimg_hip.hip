@@ -47,6 +47,7 @@ struct VimgDeviceScene {
   std::vector<void*> allocs;
   size_t total_bytes = 0;
   bool textured = false;       // needs the TEX=true kernels (cones, image textures, env map)
+  int waves_per_simd = 2;      // which register-budget build of the kernel to launch
   uint32_t num_cus = 0;
   // scratch owned by the scene: stats, work counter, host-render framebuffer
   DeviceStats* d_stats = nullptr;
@@ -222,6 +223,12 @@ struct LaunchCfg {
   uint32_t grid, lds_bytes;
 };
 
+using RenderKernel = void (*)(const DScene, const RenderArgs, float*, DeviceStats*, unsigned int*);
+RenderKernel pick_kernel(const VimgDeviceScene* s) {
+  if (s->textured) return s->waves_per_simd >= 3 ? render_kernel<true, 3> : render_kernel<true, 2>;
+  return s->waves_per_simd >= 3 ? render_kernel<false, 3> : render_kernel<false, 2>;
+}
+
 LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int sx, int sy) {
   LaunchCfg c{};
   RenderArgs& a = c.args;
@@ -248,9 +255,7 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   // persistent grid: as many 4-wave workgroups as the kernel's registers and LDS let a CU hold
   // (asked of the runtime), never more than the work
   int per_cu = 0;
-  hipError_t oe = s->textured
-      ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<true>, 256, c.lds_bytes)
-      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<false>, 256, c.lds_bytes);
+  hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_kernel(s), 256, c.lds_bytes);
   if (oe != hipSuccess || per_cu < 1) per_cu = 1;
   const uint64_t items = (sx >= 0) ? 1 : uint64_t(a.num_local_tiles) * 64u;
   const uint64_t need_blocks = (items + 255) / 256;
@@ -267,12 +272,11 @@ int launch_render(VimgDeviceScene* s, const VimgRenderParams* p, float* d_out, h
   HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(unsigned int), st));
   if (want_stats) HIP_TRY(hipMemsetAsync(s->d_stats, 0, sizeof(DeviceStats), st));
   DeviceStats* stats = want_stats ? s->d_stats : nullptr;
-  if (s->textured)
-    hipLaunchKernelGGL(render_kernel<true>, dim3(c.grid), dim3(256), c.lds_bytes, st, s->d, c.args,
-                       d_out, stats, s->d_counter);
-  else
-    hipLaunchKernelGGL(render_kernel<false>, dim3(c.grid), dim3(256), c.lds_bytes, st, s->d, c.args,
-                       d_out, stats, s->d_counter);
+  if (c.lds_bytes > 48u * 1024u)   // very deep trees: ask for the large dynamic-LDS carve-out
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(s)),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(c.lds_bytes)));
+  hipLaunchKernelGGL(pick_kernel(s), dim3(c.grid), dim3(256), c.lds_bytes, st, s->d, c.args, d_out,
+                     stats, s->d_counter);
   HIP_TRY(hipGetLastError());
   return VIMG_OK;
 }
@@ -507,6 +511,10 @@ int vimg_hip_scene_upload(const VimgScene* sc, VimgDeviceScene** out) {
                           !(sc->background.col[0] == 0.f && sc->background.col[1] == 0.f &&
                             sc->background.col[2] == 0.f);
 
+  // kernel build: scenes beyond the on-chip caches are latency-bound and want more waves per
+  // SIMD; small scenes are VALU-bound and want the build that spills least
+  s->waves_per_simd = (s->total_bytes > (32u << 20)) ? 3 : 2;
+  if (const char* e = getenv("VIMG_HIP_WAVES_PER_SIMD")) s->waves_per_simd = atoi(e);
   hipDeviceProp_t prop{};
   if (hipGetDeviceProperties(&prop, g_device) != hipSuccess) return bail(fail(VIMG_E_DEVICE, "hipGetDeviceProperties failed"));
   s->num_cus = static_cast<uint32_t>(prop.multiProcessorCount);
@@ -624,14 +632,8 @@ int vimg_hip_time_renders(VimgDeviceScene* s, const VimgRenderParams* p, void* d
     HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(unsigned int), g_stream));
     LaunchCfg c = make_launch(s, p, -1, -1);
     HIP_TRY(hipEventRecord(ev[2 * i], g_stream));
-    if (s->textured)
-      hipLaunchKernelGGL(render_kernel<true>, dim3(c.grid), dim3(256), c.lds_bytes, g_stream, s->d,
-                         c.args, static_cast<float*>(d_out), static_cast<DeviceStats*>(nullptr),
-                         s->d_counter);
-    else
-      hipLaunchKernelGGL(render_kernel<false>, dim3(c.grid), dim3(256), c.lds_bytes, g_stream, s->d,
-                         c.args, static_cast<float*>(d_out), static_cast<DeviceStats*>(nullptr),
-                         s->d_counter);
+    hipLaunchKernelGGL(pick_kernel(s), dim3(c.grid), dim3(256), c.lds_bytes, g_stream, s->d, c.args,
+                       static_cast<float*>(d_out), static_cast<DeviceStats*>(nullptr), s->d_counter);
     HIP_TRY(hipEventRecord(ev[2 * i + 1], g_stream));
   }
   HIP_TRY(hipStreamSynchronize(g_stream));
