@@ -25,7 +25,7 @@ enum {
   VIMG_OK = 0,
   VIMG_E_INVALID = -1,     /* bad argument / inconsistent scene tables */
   VIMG_E_DEVICE = -2,      /* HIP runtime error (no device, allocation, launch) */
-  VIMG_E_UNSUPPORTED = -3  /* integrator or feature not on the path */
+  VIMG_E_UNSUPPORTED = -3  /* feature outside what the path reproduces */
 };
 
 typedef struct VimgDeviceScene VimgDeviceScene;   /* opaque: device-resident scene */
@@ -47,7 +47,8 @@ int vimg_hip_scene_free(VimgDeviceScene* scene);
  * (= 64 * number of 8x8 tiles owned by tile_rank). */
 int64_t vimg_hip_shard_pixels(const VimgDeviceScene* scene, const VimgRenderParams* params);
 
-/* scene_integrator (reference include/integrators.h:36-153).
+/* scene_integrator (reference include/integrators.h:36-153) with any of the four integrators
+ * of integrator_func: s_normal, g_normal, material (src/integrators/mat_integrator.cpp), mis.
  *  d_out_rgb : DEVICE pointer.
  *      tile_world == 1: W*H float triples, linear radiance, index x + (H-1-y)*W, i.e. exactly
  *                       the reference's image_accumulated vector (include/integrators.h:113,137).

@@ -1509,6 +1509,68 @@ vec3 mis_integrator(const Ctx& c, Ray& input_ray, Pcg& rng, uint32_t depth) {
   return bounce_result;
 }
 
+// Material::eval_div_pdf dispatch (virtual, include/material/material.h:51-54): Lambertian returns
+// the texture colour (src/material/lambertian.cpp:42-45), Dielectric 1 (dielectric.cpp:86-88),
+// Principled eval/pdf through the same eval_pdf template (principled.cpp:155-158), base 0
+vec3 eval_div_pdf(const VimgScene* s, const HitInfo& hit, vec3 wi, vec3 wo, const RayCone& cone,
+                  bool regularize) {
+  const VimgMaterial& m = s->materials[hit.mat];
+  switch (m.type) {
+    case VIMG_MAT_LAMBERTIAN: return col_at_ray_hit(s, m.tex, wi, cone, hit);
+    case VIMG_MAT_DIELECTRIC: return v3(1.f);
+    case VIMG_MAT_PRINCIPLED: {
+      vec3 f;
+      float pdf;
+      principled_eval_pdf(s, m, wi, wo, hit, cone, regularize, f, pdf);
+      return f / pdf;
+    }
+    default: return vec3{0.f, 0.f, 0.f};
+  }
+}
+
+// material_integrator — reference src/integrators/mat_integrator.cpp:4-85
+vec3 material_integrator(const Ctx& c, Ray& input_ray, Pcg& rng, uint32_t depth) {
+  const VimgScene* s = c.s;
+  Ray test_ray = input_ray;
+  vec3 throughput{1.f, 1.f, 1.f};
+  constexpr uint32_t roulette_threshold = 5;
+  bool non_specular_bounce = false;
+  float eta_scale = 1;
+  for (size_t d = 0; d < depth; d++) {
+    HitInfo hit;
+    if (!bvh_hit<false>(c, test_ray, &hit))
+      return throughput * background_emit(s, test_ray.dir, test_ray.ray_cone);
+    vec3 emitted_col = mat_emitted(s->materials[hit.mat], test_ray.dir, hit.hit_n_s);
+    ScatterInfo sc = sample_mat(s, hit, test_ray.dir, rng, non_specular_bounce);
+    if (!sc.valid) return throughput * emitted_col;
+    if (!sc.is_specular) non_specular_bounce = true;
+    float hit_dist = length(test_ray.o - hit.hit_p);
+    float surface_spread_angle = spread_angle_from_curvature(
+        hit.mean_curvature, test_ray.ray_cone.cone_width, test_ray.dir, hit.hit_n_s);
+    if (sc.eta != 0.f) {
+      eta_scale /= (sc.eta * sc.eta);
+      test_ray.ray_cone = propagate_refract_cone(test_ray.ray_cone, test_ray.dir, hit.hit_p,
+                                                 surface_spread_angle, sc.eta, sc.wo);
+    } else {
+      test_ray.ray_cone
+          = propagate_reflect_cone(test_ray.ray_cone, surface_spread_angle * 2.f, hit_dist);
+    }
+    throughput *= emitted_col
+                  + eval_div_pdf(s, hit, test_ray.dir, sc.wo, test_ray.ray_cone,
+                                 non_specular_bounce);
+    if (d > roulette_threshold) {
+      float rr = static_cast<float>(pcg32_random_r(&rng)) / std::numeric_limits<uint32_t>::max();
+      vec3 rr_throughput = (1.f / eta_scale) * throughput;
+      float max_val = std::min(
+          std::max(std::max(rr_throughput.x, rr_throughput.y), rr_throughput.z), 0.95f);
+      if (rr > max_val) break;
+      throughput /= max_val;
+    }
+    test_ray = Ray(hit.hit_p, sc.wo, test_ray.ray_cone);
+  }
+  return vec3{0.f, 0.f, 0.f};
+}
+
 // shading_normal_integrator / geometric_normal_integrator — reference src/integrators/normals.cpp
 vec3 normal_integrator(const Ctx& c, Ray& input_ray, bool geometric) {
   HitInfo hit;
@@ -1525,6 +1587,7 @@ vec3 run_integrator(const Ctx& c, uint32_t func, Ray& ray, Pcg& rng, uint32_t de
   switch (func) {
     case VIMG_INTEGRATOR_S_NORMAL: return normal_integrator(c, ray, false);
     case VIMG_INTEGRATOR_G_NORMAL: return normal_integrator(c, ray, true);
+    case VIMG_INTEGRATOR_MATERIAL: return material_integrator(c, ray, rng, depth);
     default: return mis_integrator(c, ray, rng, depth);
   }
 }
@@ -1569,8 +1632,7 @@ vec3 pixel_body(const Ctx& c, const VimgRenderParams& p, size_t x, size_t y, uin
 
 bool params_ok(const VimgScene* s, const VimgRenderParams* p) {
   return s && p && p->tile_world >= 1 && p->tile_rank < p->tile_world && s->camera.res_x > 0
-         && s->camera.res_y > 0 && p->integrator != VIMG_INTEGRATOR_MATERIAL
-         && p->integrator <= VIMG_INTEGRATOR_MIS && s->bvh.max_depth + 2 <= 128;
+         && s->camera.res_y > 0 && p->integrator <= VIMG_INTEGRATOR_MIS && s->bvh.max_depth + 2 <= 128;
 }
 
 }  // namespace

@@ -294,3 +294,17 @@ def test_config2_against_the_references_own_picture():
                                "disney_spheres_agx_512_ds4.npy")).astype(np.float32)
     assert np.allclose(ours.mean(axis=(0, 1)), ref.mean(axis=(0, 1)), rtol=0.03)
     assert np.abs(ours - ref).mean() < 4.0
+
+
+def test_material_and_mis_integrators_converge_to_the_same_image():
+    """The reference ships this cross-check as pictures (renders/sphere_mis.png vs sphere_mat.png
+    vs sphere_ref.png, cornell_box_spheres): BSDF-sampling-only and MIS path tracing estimate the
+    same integral."""
+    s = scenes.json_scene("cornell_box_spheres.json", res=(120, 120))
+    mis, _, _ = O.render(s, s.default_params(samples=64))
+    mat, st, _ = O.render(s, s.default_params(integrator="material", samples=512))
+    assert st.shadow_rays == 0 and st.nan_samples == 0
+    assert np.allclose(mis.reshape(-1, 3).mean(0), mat.reshape(-1, 3).mean(0), rtol=0.01)
+    # block means agree too (the material integrator is the noisier of the two)
+    bm = lambda im: im.reshape(12, 10, 12, 10, 3).mean(axis=(1, 3))
+    assert np.abs(bm(mis) - bm(mat)).mean() < 0.02 * mis.mean()

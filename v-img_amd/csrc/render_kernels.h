@@ -1634,8 +1634,18 @@ render_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
     bool finish = false;     // this path's radiance is final
     bool at_vertex = false;  // continue with next-event estimation + BSDF sampling at `hit`
 
+    const bool material_mode = (A.integrator == VIMG_INTEGRATOR_MATERIAL);   // wave-uniform
     if (active) {
-      if (A.integrator != VIMG_INTEGRATOR_MIS) {
+      if (material_mode) {
+        // material_integrator (mat_integrator.cpp:16-23,79-81): a miss ends the path with the
+        // background; every hit, emissive or not, is a vertex
+        if (!hit_any) {
+          result = throughput * background_emit<TEX>(g, ray_d, cone);
+          finish = true;
+        } else {
+          at_vertex = true;
+        }
+      } else if (A.integrator != VIMG_INTEGRATOR_MIS) {
         // shading_normal_integrator / geometric_normal_integrator
         if (hit_any) {
           f3 n = (A.integrator == VIMG_INTEGRATOR_G_NORMAL) ? hit.ng : hit.ns;
@@ -1706,6 +1716,64 @@ render_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
         at_vertex = false;
         finish = true;
       }
+    }
+
+    // ------------------------------------------------------------------ vertex, material_integrator
+    // mat_integrator.cpp:24-78: BSDF sampling only, throughput *= emitted + eval/pdf
+    if (material_mode && at_vertex) {
+      gptr<VimgMaterial> m = g.materials + hit.mat;
+      const f3 emitted_col = mat_emitted(m, ray_d, hit.ns);
+      Scatter sc = sample_mat<TEX>(g, hit, ray_d, rng, non_specular_bounce);
+      if (!sc.valid) {
+        result = throughput * emitted_col;
+        finish = true;
+      } else {
+        if (!sc.is_specular) non_specular_bounce = true;
+        if constexpr (TEX) {
+          const float hd = length(ray_o - hit.p);
+          const float ssa = spread_angle_from_curvature(hit.curvature, cone.cone_width, ray_d, hit.ns);
+          if (sc.eta != 0.f)
+            cone = propagate_refract_cone(cone, ray_d, ssa, sc.eta, sc.wo);
+          else
+            cone = propagate_reflect_cone(cone, ssa * 2.f, hd);
+        }
+        if (sc.eta != 0.f) eta_scale /= (sc.eta * sc.eta);
+        // Material::eval_div_pdf (material.h:51-54): Lambertian -> texture colour, Dielectric -> 1,
+        // Principled -> eval / pdf of the same eval_pdf template, base -> 0
+        f3 fdiv{0.f, 0.f, 0.f};
+        const uint32_t type = m->type;
+        if (type == VIMG_MAT_LAMBERTIAN) {
+          fdiv = col_at_ray_hit<TEX>(g, m->tex, ray_d, cone, hit);
+        } else if (type == VIMG_MAT_DIELECTRIC) {
+          fdiv = splat3(1.f);
+        } else if (type == VIMG_MAT_PRINCIPLED) {
+          f3 f;
+          float pdf;
+          principled_eval_pdf<TEX>(g, m, ray_d, sc.wo, hit, cone, non_specular_bounce, f, pdf);
+          fdiv = f / pdf;
+        }
+        throughput = throughput * (emitted_col + fdiv);
+        bool survive = true;
+        if (bounce > roulette_threshold) {
+          float rr = static_cast<float>(pcg_next(rng)) / 4294967296.0f;
+          f3 rr_t = (1.f / eta_scale) * throughput;
+          float max_val = sel_min(sel_max(sel_max(rr_t.x, rr_t.y), rr_t.z), 0.95f);
+          if (rr > max_val)
+            survive = false;
+          else
+            throughput = throughput / max_val;
+        }
+        bounce += 1;
+        if (!survive || !(bounce < A.depth)) {
+          result = f3{0.f, 0.f, 0.f};   // roulette break / depth limit: return vec3(0)
+          finish = true;
+        } else {
+          ray_o = hit.p;
+          ray_d = sc.wo;
+          primary = false;
+        }
+      }
+      at_vertex = false;
     }
 
     // ------------------------------------------------------------------ vertex: NEE + BSDF

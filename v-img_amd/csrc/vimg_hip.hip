@@ -209,8 +209,8 @@ int check_params(const VimgDeviceScene* s, const VimgRenderParams* p) {
   if (p->tile_world == 0 || p->tile_rank >= p->tile_world)
     return fail(VIMG_E_INVALID, "tile_rank must be < tile_world");
   if (p->samples == 0) return fail(VIMG_E_INVALID, "samples must be > 0");
-  if (p->integrator == VIMG_INTEGRATOR_MATERIAL)
-    return fail(VIMG_E_UNSUPPORTED, "material integrator is not on the accelerated path");
+  if (p->integrator == VIMG_INTEGRATOR_MATERIAL && p->depth == 0)
+    return fail(VIMG_E_INVALID, "material integrator with depth 0 renders nothing");
   if (p->integrator > VIMG_INTEGRATOR_MIS) return fail(VIMG_E_INVALID, "unknown integrator");
   if (p->integrator == VIMG_INTEGRATOR_MIS && s->d.num_lights == 0)
     return fail(VIMG_E_INVALID, "mis integrator needs at least one light (the reference's "
