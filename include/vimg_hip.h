@@ -87,6 +87,15 @@ int vimg_hip_assemble_shards(const VimgDeviceScene* scene, uint32_t world,
 int vimg_hip_time_renders(VimgDeviceScene* scene, const VimgRenderParams* params, void* d_out_rgb,
                           int steps, float* ms_per_launch);
 
+/* Post chain of reference src/main.cpp:304-356 on the GPU: tonemapper 0 clamp (simple_clamp),
+ * 1 AgX (src/tonemap/agx.cpp), 2 Reinhard on the image's largest luminance
+ * (src/tonemap/reinhard.cpp), 3 ACES (src/tonemap/aces.cpp); then sRGB_gamma_correction
+ * (include/color_utils.h:45-68) and the 8-bit quantisation with NaN -> magenta.
+ * d_rgb: DEVICE, w*h float triples; d_rgb8: DEVICE, w*h byte triples.  Saves the 12 B/pixel
+ * download when only the picture is wanted. */
+int vimg_hip_post_rgb8(const void* d_rgb, int w, int h, int tonemapper, void* d_rgb8,
+                       void* stream);
+
 /* Bytes of HBM the uploaded scene occupies. */
 int64_t vimg_hip_scene_bytes(const VimgDeviceScene* scene);
 

@@ -1639,6 +1639,107 @@ bool params_ok(const VimgScene* s, const VimgRenderParams* p) {
 
 extern "C" {
 
+// ---- post chain: tonemap -> sRGB OETF -> 8-bit quantise
+//   simple_clamp / sRGB_gamma_correction  reference include/color_utils.h:21-68
+//   agx                                    reference src/tonemap/agx.cpp:6-90
+//   reinhard_lum                           reference src/tonemap/reinhard.cpp:3-35
+//   aces                                   reference src/tonemap/aces.cpp:5-29
+//   quantise, NaN -> magenta               reference src/main.cpp:339-356
+}  // extern "C" (helpers below are C++)
+namespace {
+#if defined(ORACLE_LIBM_FLOAT) && ORACLE_LIBM_FLOAT
+inline float F_pow(float x, float y) { return ::powf(x, y); }
+#else
+inline float F_pow(float x, float y) {
+  return static_cast<float>(::pow(static_cast<double>(x), static_cast<double>(y)));
+}
+#endif
+inline vec3 mat3_mul(const float m[9], vec3 v) {   // glm column-major mat3 * vec3
+  return vec3{m[0] * v.x + m[3] * v.y + m[6] * v.z, m[1] * v.x + m[4] * v.y + m[7] * v.z,
+              m[2] * v.x + m[5] * v.y + m[8] * v.z};
+}
+vec3 agx_pixel(vec3 val) {
+  static const float agx_mat[9] = {0.842479062253094, 0.0423282422610123, 0.0423756549057051,
+                                   0.0784335999999992, 0.878468636469772, 0.0784336,
+                                   0.0792237451477643, 0.0791661274605434, 0.879142973793104};
+  static const float agx_mat_inv[9] = {1.19687900512017, -0.0528968517574562, -0.0529716355144438,
+                                       -0.0980208811401368, 1.15190312990417, -0.0980434501171241,
+                                       -0.0990297440797205, -0.0989611768448433, 1.15107367264116};
+  const float min_ev = -12.47393f, max_ev = 4.026069f;
+  val = mat3_mul(agx_mat, val);
+  val = vec3{clampf(F_log2(val.x), min_ev, max_ev), clampf(F_log2(val.y), min_ev, max_ev),
+             clampf(F_log2(val.z), min_ev, max_ev)};
+  val = (val - min_ev) / (max_ev - min_ev);
+  {   // agxDefaultContrastApprox
+    vec3 x = val, x2 = x * x, x4 = x2 * x2;
+    val = v3(+15.5f) * x4 * x2 - v3(40.14f) * x4 * x + v3(31.96f) * x4 - v3(6.868f) * x2 * x
+          + v3(0.4298f) * x2 + v3(0.1191f) * x - v3(0.00232f);
+  }
+  {   // agxLook, default look: pow(val*1+0, 1) is val; luma + 1*(val - luma)
+    float luma = luminance(val);
+    val = vec3{luma + 1.0f * (val.x - luma), luma + 1.0f * (val.y - luma), luma + 1.0f * (val.z - luma)};
+  }
+  val = mat3_mul(agx_mat_inv, val);
+  if (val.x < 0.f) val.x = 0.f;
+  if (val.y < 0.f) val.y = 0.f;
+  if (val.z < 0.f) val.z = 0.f;
+  return vec3{F_pow(val.x, 2.2f), F_pow(val.y, 2.2f), F_pow(val.z, 2.2f)};
+}
+vec3 aces_pixel(vec3 v) {
+  static const float in_m[9] = {0.59719f, 0.07600f, 0.02840f, 0.35458f, 0.90834f,
+                                0.13383f, 0.04823f, 0.01566f, 0.83777f};
+  static const float out_m[9] = {1.60475f,  -0.10208f, -0.00327f, -0.53108f, 1.10813f,
+                                 -0.07276f, -0.07367f, -0.00605f, 1.07602f};
+  v = mat3_mul(in_m, v);
+  vec3 a = v * (v + 0.0245786f) - 0.000090537f;
+  vec3 b = v * (0.983729f * v + 0.4329510f) + 0.238081f;
+  v = a / b;
+  return mat3_mul(out_m, v);
+}
+inline float srgb_oetf(float x) {
+  x = clampf(x, 0.0f, 1.0f);
+  if (x < 0.0031308f) return x * 12.92f;
+  return 1.055f * F_pow(x, 1.0f / 2.4f) - 0.055f;
+}
+}  // namespace
+extern "C" {
+
+int oracle_post_rgb8(const float* rgb, int w, int h, int tonemapper, uint8_t* out) {
+  if (!rgb || !out || w <= 0 || h <= 0 || tonemapper < 0 || tonemapper > 3) return -1;
+  const size_t n = static_cast<size_t>(w) * h;
+  float largest_L = 0.0f;
+  if (tonemapper == 2)
+    for (size_t i = 0; i < n; ++i) {
+      float l = luminance(load3(rgb + 3 * i));
+      if (l > largest_L) largest_L = l;
+    }
+  for (size_t i = 0; i < n; ++i) {
+    vec3 c = load3(rgb + 3 * i);
+    switch (tonemapper) {
+      case 0: c = vec3{clampf(c.x, 0.f, 1.f), clampf(c.y, 0.f, 1.f), clampf(c.z, 0.f, 1.f)}; break;
+      case 1: c = agx_pixel(c); break;
+      case 2: {
+        float in_L = luminance(c);
+        float numerator = in_L * (1.0f + (in_L / (largest_L * largest_L)));
+        float new_L = numerator / (1.0f + in_L);
+        c = (in_L > 0.f) ? c * (new_L / in_L) : vec3{0.f, 0.f, 0.f};
+        break;
+      }
+      default: c = aces_pixel(c); break;
+    }
+    c = vec3{srgb_oetf(c.x), srgb_oetf(c.y), srgb_oetf(c.z)};
+    uint8_t* o = out + 3 * i;
+    if (std::isnan(c.x) || std::isnan(c.y) || std::isnan(c.z)) {
+      o[0] = 255, o[1] = 0, o[2] = 255;
+    } else {
+      o[0] = static_cast<uint8_t>(clampi(static_cast<int>(255.999 * c.x), 0, 255));
+      o[1] = static_cast<uint8_t>(clampi(static_cast<int>(255.999 * c.y), 0, 255));
+      o[2] = static_cast<uint8_t>(clampi(static_cast<int>(255.999 * c.z), 0, 255));
+    }
+  }
+  return 0;
+}
+
 int oracle_uses_float_libm(void) {
 #if defined(ORACLE_LIBM_FLOAT) && ORACLE_LIBM_FLOAT
   return 1;

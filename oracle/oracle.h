@@ -51,6 +51,10 @@ enum {
 };
 int oracle_probe(const VimgScene* scene, int kind, int n, const float* in, float* out);
 
+/* Post chain of the reference (tonemapper 0 clamp, 1 AgX, 2 Reinhard, 3 ACES; then sRGB OETF and
+ * 8-bit quantisation with NaN -> magenta): reference src/main.cpp:304-356. */
+int oracle_post_rgb8(const float* rgb, int w, int h, int tonemapper, uint8_t* out_rgb8);
+
 /* 1 when built with -DORACLE_LIBM_FLOAT (the reference's own float libm calls) */
 int oracle_uses_float_libm(void);
 

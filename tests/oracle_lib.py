@@ -39,6 +39,8 @@ def load(name="liboracle.so"):
         lib.oracle_probe.restype = C.c_int
         lib.oracle_probe.argtypes = [abi.PScene, C.c_int, C.c_int, abi.Pf32, abi.Pf32]
         lib.oracle_uses_float_libm.restype = C.c_int
+        lib.oracle_post_rgb8.restype = C.c_int
+        lib.oracle_post_rgb8.argtypes = [abi.Pf32, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
         _libs[name] = lib
     return _libs[name]
 
@@ -101,3 +103,13 @@ def r2(n, lib=None):
     out = (C.c_float * 2)()
     lib.oracle_random_x_y_r2(n, out)
     return float(out[0]), float(out[1])
+
+
+def post_rgb8(image, tonemapper, lib=None):
+    lib = lib or load()
+    img = np.ascontiguousarray(image, dtype=np.float32)
+    out = np.empty(img.shape, dtype=np.uint8)
+    if lib.oracle_post_rgb8(img.ctypes.data_as(abi.Pf32), img.shape[1], img.shape[0], tonemapper,
+                            out.ctypes.data_as(C.POINTER(C.c_uint8))):
+        raise RuntimeError("oracle_post_rgb8 rejected its arguments")
+    return out

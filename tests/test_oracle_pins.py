@@ -308,3 +308,25 @@ def test_material_and_mis_integrators_converge_to_the_same_image():
     # block means agree too (the material integrator is the noisier of the two)
     bm = lambda im: im.reshape(12, 10, 12, 10, 3).mean(axis=(1, 3))
     assert np.abs(bm(mis) - bm(mat)).mean() < 0.02 * mis.mean()
+
+
+def test_post_chain_restatement():
+    """oracle_post_rgb8 (reference src/main.cpp:304-356) on closed-form inputs, and against the
+    host library's post chain (two independent restatements of the same lines)."""
+    img = np.zeros((2, 4, 3), np.float32)
+    img[0, 1] = 0.0031308 * 0.5
+    img[0, 2] = 0.5
+    img[0, 3] = 7.0
+    img[1, 0] = np.nan
+    out = O.post_rgb8(img, 0)
+    lin = np.float32(0.0031308 * 0.5) * np.float32(12.92)
+    assert out[0, 0].tolist() == [0, 0, 0] and out[0, 3].tolist() == [255, 255, 255]
+    assert out[0, 1].tolist() == [int(255.999 * float(lin))] * 3
+    assert out[0, 2].tolist() == [int(255.999 * (1.055 * 0.5 ** (1 / 2.4) - 0.055))] * 3
+    assert out[1, 0].tolist() == [255, 0, 255]
+    s = scenes.json_scene("disney_spheres.json", res=(180, 80))
+    hdr, _, _ = O.render(s, s.default_params(samples=8))
+    for tm in range(4):
+        a = O.post_rgb8(hdr, tm).astype(int)
+        b = vimg_amd.tonemap_to_rgb8(hdr, tm).astype(int)
+        assert np.abs(a - b).max() <= 1 and (a == b).mean() > 0.999

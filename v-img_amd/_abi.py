@@ -171,6 +171,8 @@ HIP_SYMBOLS = {
     "vimg_hip_assemble_shards": (C.c_int, [C.c_void_p, u32, i64, C.c_void_p, C.c_void_p,
                                            C.c_void_p]),
     "vimg_hip_time_renders": (C.c_int, [C.c_void_p, PParams, C.c_void_p, C.c_int, Pf32]),
+    "vimg_hip_post_rgb8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                    C.c_void_p]),
     "vimg_hip_scene_bytes": (i64, [C.c_void_p]),
     "vimg_hip_last_error": (C.c_char_p, []),
 }

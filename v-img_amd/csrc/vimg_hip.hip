@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/vimg_hip.h"
+#include "post_kernels.h"
 #include "render_kernels.h"
 
 using namespace vimg;
@@ -639,6 +640,30 @@ int vimg_hip_time_renders(VimgDeviceScene* s, const VimgRenderParams* p, void* d
   HIP_TRY(hipStreamSynchronize(g_stream));
   for (int i = 0; i < steps; ++i) HIP_TRY(hipEventElapsedTime(&ms_per_launch[i], ev[2 * i], ev[2 * i + 1]));
   for (auto& e : ev) (void)hipEventDestroy(e);
+  return VIMG_OK;
+}
+
+int vimg_hip_post_rgb8(const void* d_rgb, int w, int h, int tonemapper, void* d_rgb8, void* stream) {
+  if (!d_rgb || !d_rgb8 || w <= 0 || h <= 0 || tonemapper < 0 || tonemapper > 3)
+    return fail(VIMG_E_INVALID, "post_rgb8: bad arguments");
+  if (g_device < 0) {
+    int rc = vimg_hip_init(0);
+    if (rc) return rc;
+  }
+  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : g_stream;
+  const size_t n = size_t(w) * h;
+  static unsigned int* d_max = nullptr;
+  if (!d_max) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_max), sizeof(unsigned int)));
+  if (tonemapper == 2) {
+    HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(unsigned int), st));
+    hipLaunchKernelGGL(post_max_luminance_kernel, dim3(1024), dim3(256), 0, st,
+                       static_cast<const float*>(d_rgb), n, d_max);
+  }
+  hipLaunchKernelGGL(post_rgb8_kernel, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0,
+                     st, static_cast<const float*>(d_rgb), n, tonemapper, d_max,
+                     static_cast<unsigned char*>(d_rgb8));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));
   return VIMG_OK;
 }
 

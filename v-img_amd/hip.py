@@ -134,4 +134,16 @@ class DeviceScene:
             pass
 
 
-__all__ = ["DeviceScene", "HipError", "device_count", "init", "make_params"]
+def post_rgb8(image, tonemapper=1, stream=None):
+    """Tonemap + sRGB + 8-bit quantise a [H, W, 3] float32 CUDA tensor on the GPU
+    (vimg_hip_post_rgb8); returns a [H, W, 3] uint8 CUDA tensor."""
+    import torch
+    h, w = image.shape[0], image.shape[1]
+    out = torch.empty((h, w, 3), dtype=torch.uint8, device=image.device)
+    sp = C.c_void_p(stream.cuda_stream) if stream is not None else None
+    _check(_lib().vimg_hip_post_rgb8(C.c_void_p(image.data_ptr()), w, h, tonemapper,
+                                     C.c_void_p(out.data_ptr()), sp))
+    return out
+
+
+__all__ = ["DeviceScene", "post_rgb8", "HipError", "device_count", "init", "make_params"]
