@@ -22,10 +22,11 @@ ORAFLAGS  := -std=c++20 -O3 -march=x86-64-v3 -fPIC -shared -ffp-contract=off -pt
 HIPFLAGS  := --offload-arch=$(ARCH) -std=c++20 -O3 -fPIC -shared -ffp-contract=off \
              -fno-fast-math -Iinclude -Wall -Wno-unused-function
 
-all: host hip oracle
+all: host hip oracle cli
 host: $(LIBDIR)/libvimg_host.so
 hip: $(LIBDIR)/libvimg_hip.so
 oracle: oracle/liboracle.so
+cli: v-img_amd/bin/vimg-amd
 
 $(LIBDIR)/libvimg_host.so: $(HOSTSRC) $(HOSTHDR) Makefile
 	@mkdir -p $(LIBDIR)
@@ -34,6 +35,12 @@ $(LIBDIR)/libvimg_host.so: $(HOSTSRC) $(HOSTHDR) Makefile
 $(LIBDIR)/libvimg_hip.so: $(HIPSRC) $(HIPHDR) Makefile
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) $(HIPSRC) -o $@
+
+# C++ host program (the counterpart of the reference's main): links both libraries by rpath
+v-img_amd/bin/vimg-amd: v-img_amd/cli/main.cpp $(LIBDIR)/libvimg_host.so $(LIBDIR)/libvimg_hip.so Makefile
+	@mkdir -p v-img_amd/bin
+	$(HIPCC) -std=c++20 -O2 -Iinclude v-img_amd/cli/main.cpp -L$(LIBDIR) -lvimg_host -lvimg_hip \
+	  -Wl,-rpath,'$$ORIGIN/../lib' -o $@
 
 oracle/liboracle.so: $(ORASRC) $(ORAHDR) Makefile
 	$(CXX) $(ORAFLAGS) $(ORASRC) -o $@
@@ -46,4 +53,4 @@ oracle/liboracle_libmf.so: $(ORASRC) $(ORAHDR) Makefile
 clean:
 	rm -f $(LIBDIR)/*.so oracle/*.so
 
-.PHONY: all host hip oracle clean
+.PHONY: all host hip oracle cli clean

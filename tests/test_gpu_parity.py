@@ -306,3 +306,31 @@ def test_post_chain_on_gpu_is_byte_exact(tonemapper):
     # the other three carry the NaN to the magenta marker
     assert got[0, 0].tolist() == ([0, 0, 0] if tonemapper == 2 else [255, 0, 255])
     assert np.array_equal(got, want)
+
+
+def test_cpp_host_program_end_to_end(tmp_path):
+    """v-img_amd/bin/vimg-amd: the C++ host (JSON loading, SAH BVH, PNG) around the C ABI —
+    same picture as the Python path, and the -d single-pixel flag."""
+    import os
+    import subprocess
+    import vimg_amd
+    from vimg_amd import hip
+    from PIL import Image
+    exe = os.path.join(vimg_amd.abi.PKG_DIR, "bin", "vimg-amd")
+    scene = os.path.join(scenes.SCENES, "cornell_box_spheres.json")
+    out = str(tmp_path / "cli.png")
+    r = subprocess.run([exe, "-f", scene, "-s", "4", "-c", "1", "-b", "1", "-o", out],
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Mrays/s" in r.stdout
+    s = scenes.json_scene("cornell_box_spheres.json")
+    hdr, _ = _dev(s).render(s.default_params(samples=4))
+    want = hip.post_rgb8(hdr, 1).cpu().numpy()
+    assert np.array_equal(np.asarray(Image.open(out)), want)
+    r = subprocess.run([exe, "-f", scene, "-s", "4", "-b", "1", "-d", "400 300"],
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "Value of pixel in linear space" in r.stdout
+    px = _dev(s).trace_pixel(s.default_params(samples=4), 400, 300)
+    vals = [float(v) for v in r.stdout.split("(")[-1].split(")")[0].split(",")]
+    assert np.allclose(vals, px, rtol=1e-6)
+    assert subprocess.run([exe, "-f", "/no/such.json"], capture_output=True).returncode == 1
