@@ -53,11 +53,13 @@ struct __attribute__((aligned(16))) DLeafPrim {
 static_assert(sizeof(DLeafPrim) == 48, "DLeafPrim must be 48 bytes");
 
 // Per-triangle shading record, 64 B (positions again so hit_info needs no second indirection).
+// `n` is normalize(cross(p1-p0, p2-p0)) — a function of the vertices only, evaluated once at
+// upload with the float expression the reference evaluates per hit (src/geometry/triangle.cpp:25).
 struct __attribute__((aligned(16))) DTriShade {
   float p[9];
   uint32_t mesh;
   uint32_t i0, i1, i2;   // global vertex ids (normals / uv lookup)
-  uint32_t pad[3];
+  float n[3];
 };
 static_assert(sizeof(DTriShade) == 64, "DTriShade must be 64 bytes");
 
@@ -79,6 +81,7 @@ struct DScene {
   // primitives / shading data
   gptr<VimgPrim> prims;
   gptr<DTriShade> tri_shade;
+  gptr<float> tri_area_pdf;   // 1 / (|cross(e2, e1)| / 2) per triangle (triangle.cpp:229-231,246)
   gptr<VimgMesh> meshes;
   gptr<float> normals;
   gptr<float> uvs;

@@ -639,7 +639,7 @@ VD void tri_hit_info(const DScene& g, uint32_t tri, const HitRec& rec, uint32_t 
   const uint32_t mflags = g.material_flags[mat];
   f3 edge1 = p1 - p0, edge2 = p2 - p0;
   float u = rec.e0 * rec.inv_det, v = rec.e1 * rec.inv_det, w = rec.e2 * rec.inv_det;
-  const f3 tri_normal = normalize(cross(edge1, edge2));
+  const f3 tri_normal{ts->n[0], ts->n[1], ts->n[2]};   // normalize(cross(edge1, edge2)), baked
   f3 n0 = tri_normal, n1 = tri_normal, n2 = tri_normal, shading_normal = tri_normal;
   if (mesh->has_normals) {
     n0 = load3(g.normals + 3 * size_t(i0));
@@ -1269,7 +1269,7 @@ VD void tri_light_sample(const DScene& g, uint32_t tri, f3 look_from, Rng& rng, 
       p2{ts->p[6], ts->p[7], ts->p[8]};
   gptr<VimgMesh> mesh = g.meshes + ts->mesh;
   const f3 edge1 = p1 - p0, edge2 = p2 - p0;
-  f3 tri_normal = normalize(cross(edge1, edge2));
+  f3 tri_normal{ts->n[0], ts->n[1], ts->n[2]};   // normalize(cross(edge1, edge2)), baked
   f3 n0 = tri_normal, n1 = tri_normal, n2 = tri_normal;
   if (mesh->has_normals) {
     n0 = load3(g.normals + 3 * size_t(ts->i0));
@@ -1292,21 +1292,14 @@ VD void tri_light_sample(const DScene& g, uint32_t tri, f3 look_from, Rng& rng, 
   f3 dir_vec = hit_p - look_from;
   float dist2 = length2(dir_vec);
   dir_vec = normalize(dir_vec);
-  float area = length(cross(edge2, edge1)) / 2.0f;
-  float pdf = 1.f / area;
+  float pdf = g.tri_area_pdf[tri];   // 1.f / (length(cross(edge2, edge1)) / 2.0f), baked
   float cosine = absf(dot(hit_n, -dir_vec));
   float G = cosine / dist2;
   info = EmitterInfo{dir_vec, pdf, sqrt_f(dist2), G};
   le = mat_emitted(g.materials + mesh->material, info.wi, hit_n);
 }
 // Triangle::surf_pdf: reference src/geometry/triangle.cpp:235-248
-VD float tri_surf_pdf(const DScene& g, uint32_t tri) {
-  gptr<DTriShade> ts = g.tri_shade + tri;
-  const f3 p0{ts->p[0], ts->p[1], ts->p[2]}, p1{ts->p[3], ts->p[4], ts->p[5]},
-      p2{ts->p[6], ts->p[7], ts->p[8]};
-  float area = length(cross(p2 - p0, p1 - p0)) / 2.0f;
-  return 1.f / area;
-}
+VD float tri_surf_pdf(const DScene& g, uint32_t tri) { return g.tri_area_pdf[tri]; }
 // Sphere::sample: reference src/geometry/sphere.cpp:58-118 (cone construction of quirk Q16 kept)
 VD void sphere_light_sample(const DScene& g, gptr<VimgSphere> sp, f3 look_from, Rng& rng, f3& le,
                             EmitterInfo& info) {

@@ -424,6 +424,7 @@ int vimg_hip_scene_upload(const VimgScene* sc, VimgDeviceScene** out) {
 
   // ---- per-triangle shading records and leaf slots
   std::vector<DTriShade> shade(sc->num_tris);
+  std::vector<float> area_pdf(sc->num_tris);
   for (uint32_t t = 0; t < sc->num_tris; ++t) {
     const VimgMesh& m = sc->meshes[sc->tri_mesh[t]];
     DTriShade ts{};
@@ -434,6 +435,21 @@ int vimg_hip_scene_upload(const VimgScene* sc, VimgDeviceScene** out) {
     const uint32_t ids[3] = {ts.i0, ts.i1, ts.i2};
     for (int k = 0; k < 3; ++k)
       for (int a = 0; a < 3; ++a) ts.p[k * 3 + a] = sc->vertices[size_t(ids[k]) * 3 + a];
+    {
+      // tri_normal and the area pdf with the reference's float expressions
+      // (src/geometry/triangle.cpp:19-25,229-231; glm cross / normalize as in device_math.h)
+      const float* v = ts.p;
+      const float e1[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]};
+      const float e2[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
+      const float c12[3] = {e1[1] * e2[2] - e2[1] * e1[2], e1[2] * e2[0] - e2[2] * e1[0],
+                            e1[0] * e2[1] - e2[0] * e1[1]};
+      const float inv_len = 1.0f / std::sqrt(c12[0] * c12[0] + c12[1] * c12[1] + c12[2] * c12[2]);
+      for (int a = 0; a < 3; ++a) ts.n[a] = c12[a] * inv_len;
+      const float c21[3] = {e2[1] * e1[2] - e1[1] * e2[2], e2[2] * e1[0] - e1[2] * e2[0],
+                            e2[0] * e1[1] - e1[0] * e2[1]};
+      const float area = std::sqrt(c21[0] * c21[0] + c21[1] * c21[1] + c21[2] * c21[2]) / 2.0f;
+      area_pdf[t] = 1.f / area;
+    }
     shade[t] = ts;
   }
   std::vector<DLeafPrim> leaf(sc->num_prims);
@@ -492,6 +508,7 @@ int vimg_hip_scene_upload(const VimgScene* sc, VimgDeviceScene** out) {
   UP(leaf_prims, leaf.data(), leaf.size());
   UP(prims, sc->prims, sc->num_prims);
   UP(tri_shade, shade.data(), shade.size());
+  UP(tri_area_pdf, area_pdf.data(), area_pdf.size());
   UP(meshes, sc->meshes, sc->num_meshes);
   UP(normals, sc->normals, size_t(sc->num_vertices) * 3);
   UP(uvs, sc->uvs, sc->num_uvs * 2);
