@@ -16,7 +16,10 @@ cases = {
     "config4 (2 displaced meshes 627K tris, normal map, HDRI, thin lens, 1366x768)": lambda: scenes.config4_scene(),
     "config5 (1.0M tris, mip-mapped textures, normal maps, RG map, 1366x768)": lambda: scenes.config5_scene(n=700),
 }
+only = sys.argv[2] if len(sys.argv) > 2 else ""
 for name, mk in cases.items():
+    if only and only not in name:
+        continue
     t0 = time.perf_counter(); s = mk(); t_build = time.perf_counter() - t0
     t0 = time.perf_counter(); d = hip.DeviceScene(s); t_up = time.perf_counter() - t0
     v = s.view.contents
