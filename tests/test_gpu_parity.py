@@ -334,3 +334,89 @@ def test_cpp_host_program_end_to_end(tmp_path):
     vals = [float(v) for v in r.stdout.split("(")[-1].split(")")[0].split(",")]
     assert np.allclose(vals, px, rtol=1e-6)
     assert subprocess.run([exe, "-f", "/no/such.json"], capture_output=True).returncode == 1
+
+
+def test_axis_aligned_rays_take_the_exact_slab_path():
+    """Rays with a zero direction component make 0 * inf = NaN possible in the slab test; the
+    reference's (a<b)?b:a selects then propagate the NaN differently from v_min/v_max.  The
+    kernel switches to the select form for such rays: hits and occlusion must equal the oracle's,
+    including origins that lie exactly on bounding-box planes."""
+    s = scenes.json_scene("disney_spheres.json")
+    d = _dev(s)
+    rng = np.random.default_rng(11)
+    dirs = np.array([[0, 0, -1], [0, 0, 1], [1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0],
+                     [0, 0.6, -0.8], [0.6, 0, -0.8], [0.6, 0.8, 0]], dtype=np.float32)
+    # origins: random interior points, plus coordinates snapped onto box planes of the scene
+    planes = np.array([-650, 650, -277.5, 277.5, 277, -77.5, -300, 300, 0, -177.5, -200, 40],
+                      dtype=np.float32)
+    o = rng.uniform(-600, 600, (3000, 3)).astype(np.float32)
+    o[:, 1] = rng.uniform(-270, 270, 3000)
+    o[:, 2] = rng.uniform(-270, 270, 3000)
+    snap = rng.random((3000, 3)) < 0.4
+    o[snap] = rng.choice(planes, snap.sum())
+    rays = np.concatenate([o, dirs[rng.integers(0, len(dirs), 3000)]], 1)
+    hg, hc = d.probe(O.PROBE_CLOSEST_HIT, rays), O.probe(s, O.PROBE_CLOSEST_HIT, rays)
+    assert np.array_equal(hg[:, :4], hc[:, :4])                     # hit flag, t, prim, material
+    assert hc[:, 0].sum() > 1000
+    occ = np.concatenate([rays, rng.uniform(1, 1500, (3000, 1)).astype(np.float32)], 1)
+    assert np.array_equal(d.probe(O.PROBE_OCCLUDED, occ), O.probe(s, O.PROBE_OCCLUDED, occ))
+
+
+def test_scene_validation_rejects_broken_tables():
+    """vimg_hip_scene_upload checks every index before anything reaches a kernel."""
+    import ctypes as C
+    from vimg_amd import abi, hip
+    s = scenes.json_scene("disney_spheres.json", res=(32, 16))
+    lib = abi.hip_lib()
+
+    def upload(mutate):
+        view = abi.Scene()
+        C.memmove(C.byref(view), s.view, C.sizeof(view))
+        keep = mutate(view)
+        h = C.c_void_p()
+        rc = lib.vimg_hip_scene_upload(C.byref(view), C.byref(h))
+        if rc == 0:
+            lib.vimg_hip_scene_free(h)
+        return rc, lib.vimg_hip_last_error().decode(), keep
+
+    def bad_prim(v):
+        arr = (abi.Prim * v.num_prims)(*[v.prims[i] for i in range(v.num_prims)])
+        arr[3].index = 9999
+        v.prims = C.cast(arr, C.POINTER(abi.Prim))
+        return arr
+
+    def bad_node(v):
+        n = v.bvh.num_nodes
+        arr = (abi.BVHNode * n)(*[v.bvh.nodes[i] for i in range(n)])
+        arr[1].first_index = 1          # a cycle: node 1 points at itself
+        v.bvh.nodes = C.cast(arr, C.POINTER(abi.BVHNode))
+        return arr
+
+    def bad_light(v):
+        arr = (abi.Light * v.num_lights)(*[v.lights[i] for i in range(v.num_lights)])
+        arr[0].prim = 500
+        v.lights = C.cast(arr, C.POINTER(abi.Light))
+        return arr
+
+    def bad_material(v):
+        arr = (abi.Material * v.num_materials)(*[v.materials[i] for i in range(v.num_materials)])
+        arr[0].tex = 77
+        v.materials = C.cast(arr, C.POINTER(abi.Material))
+        return arr
+
+    for mut in (bad_prim, bad_node, bad_light, bad_material):
+        rc, msg, _ = upload(mut)
+        assert rc == -1 and msg, (mut.__name__, rc, msg)
+    assert upload(lambda v: None)[0] == 0
+    # mis needs a light
+    def no_lights(v):
+        v.num_lights = 0
+    view = abi.Scene()
+    C.memmove(C.byref(view), s.view, C.sizeof(view))
+    view.num_lights = 0
+    h = C.c_void_p()
+    assert lib.vimg_hip_scene_upload(C.byref(view), C.byref(h)) == 0
+    p = s.default_params(samples=1)
+    out = np.zeros((16, 32, 3), np.float32)
+    assert lib.vimg_hip_render_to_host(h, C.byref(p), out.ctypes.data_as(abi.Pf32), None) == -1
+    lib.vimg_hip_scene_free(h)
