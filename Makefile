@@ -36,6 +36,13 @@ $(LIBDIR)/libvimg_hip.so: $(HIPSRC) $(HIPHDR) Makefile
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) $(HIPSRC) -o $@
 
+# measurement build: stage timers (s_memtime) inside render_pool_kernel; never the product library,
+# selected with VIMG_HIP_LIB by tools/stage_profile.py
+prof: v-img_amd/lib/prof/libvimg_hip.so
+v-img_amd/lib/prof/libvimg_hip.so: $(HIPSRC) $(HIPHDR) Makefile
+	@mkdir -p v-img_amd/lib/prof
+	$(HIPCC) $(HIPFLAGS) -DVIMG_PROFILE=1 $(HIPSRC) -o $@
+
 # C++ host program (the counterpart of the reference's main): links both libraries by rpath
 v-img_amd/bin/vimg-amd: v-img_amd/cli/main.cpp $(LIBDIR)/libvimg_host.so $(LIBDIR)/libvimg_hip.so Makefile
 	@mkdir -p v-img_amd/bin
@@ -53,4 +60,4 @@ oracle/liboracle_libmf.so: $(ORASRC) $(ORAHDR) Makefile
 clean:
 	rm -f $(LIBDIR)/*.so oracle/*.so
 
-.PHONY: all host hip oracle cli clean
+.PHONY: all host hip oracle cli clean prof

@@ -72,6 +72,33 @@ def test_image_matches_oracle_json_scenes(name, res, spp, depth):
     assert gst.nan_samples == cst.nan_samples
 
 
+@pytest.mark.parametrize("scene_name", ["disney_spheres.json", "glass_in_box.json", "feature"])
+def test_both_render_kernels_give_the_same_bits(scene_name, monkeypatch):
+    """render_kernel (one path per lane) and render_pool_kernel (paths pooled in LDS) are two
+    schedules of the same per-path arithmetic: identical images, identical event counts, whichever
+    the upload policy would pick for the scene; trace_pixel and shards included."""
+    if scene_name == "feature":
+        s = scenes.feature_scene(res=(72, 48), envmap=True, lens=True)
+        p = s.default_params(samples=6, depth=7)
+    else:
+        s = scenes.json_scene(scene_name, res=(136, 72))
+        p = s.default_params(samples=12)
+    out = {}
+    for pool in ("0", "1"):
+        monkeypatch.setenv("VIMG_HIP_POOL", pool)
+        d = _dev(s)
+        img, st = d.render_to_host(p)
+        px = d.trace_pixel(p, 17, 23)
+        out[pool] = (img, st, px)
+    a, b = out["0"], out["1"]
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+    assert np.array_equal(np.asarray(a[2]).view(np.uint32), np.asarray(b[2]).view(np.uint32))
+    assert a[1].as_dict() == b[1].as_dict()
+    cpu, cst, _ = O.render(s, p)
+    _compare_images(b[0], cpu, scene_name + " (pooled kernel)")
+    assert b[1].paths == cst.paths
+
+
 @pytest.mark.parametrize("integrator", ["s_normal", "g_normal"])
 def test_normal_integrators_bit_exact(integrator):
     # BASELINE config 1: glass_in_box with the 'normal' integrator (no transcendental on the path)

@@ -80,6 +80,7 @@ struct DScene {
 
   // primitives / shading data
   gptr<VimgPrim> prims;
+  gptr<uint32_t> prim_class;   // per primitive: 1 Lambertian, 2 Principled, 0 anything else
   gptr<DTriShade> tri_shade;
   gptr<float> tri_area_pdf;   // 1 / (|cross(e2, e1)| / 2) per triangle (triangle.cpp:229-231,246)
   gptr<VimgMesh> meshes;
@@ -112,12 +113,22 @@ struct RenderArgs {
   uint32_t full_stats;
   uint32_t stack_entries;           // per-lane LDS stack depth (max_depth + 2)
   uint32_t lds_nodes;               // number of top-of-tree nodes staged into LDS
+  uint32_t pool_slots;              // pooled kernel: path slots per wave (0 = lane-bound kernel)
+  uint32_t pool_refill;             // pooled kernel: finished rays that trigger a refill pass
+  uint32_t pool_vbatch;             // pooled kernel: queued slots of one class that start a vertex batch
+  uint32_t pool_classes;            // pooled kernel: 1 = one vertex queue, 2 = Principled apart, 3 = + Lambertian apart
   int32_t single_x, single_y;       // trace_pixel mode when >= 0
 };
 
 struct DeviceStats {
   unsigned long long closest, shadow, internal, leaf, prim, sphere, nan_samples;
   unsigned long long trip_descend, trip_prim, iterations;   // wave-level loop trips (diagnostic)
+  // -DVIMG_PROFILE builds only (make prof): s_memtime cycles of wave 0.. summed over waves, per
+  // stage of render_pool_kernel, and lanes switched on per vertex batch
+  unsigned long long prof[16];
 };
+enum : int { PF_TOTAL = 0, PF_V_LOAD, PF_V_LIGHT, PF_V_SAMPLE, PF_V_EVAL, PF_V_FINISH, PF_V_STORE,
+             PF_W_REFILL, PF_W_BOX, PF_W_LEAF, PF_W_RETIRE, PF_V_BATCHES, PF_V_LANES, PF_V_ATVERTEX,
+             PF_W_ROUNDS, PF_COUNT };
 
 }  // namespace vimg

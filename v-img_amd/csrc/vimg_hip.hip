@@ -16,6 +16,7 @@
 #include "../../include/vimg_hip.h"
 #include "post_kernels.h"
 #include "render_kernels.h"
+#include "render_pool_kernel.h"
 
 using namespace vimg;
 
@@ -49,6 +50,7 @@ struct VimgDeviceScene {
   size_t total_bytes = 0;
   bool textured = false;       // needs the TEX=true kernels (cones, image textures, env map)
   int waves_per_simd = 2;      // which register-budget build of the kernel to launch
+  bool pooled = false;         // render_pool_kernel (LDS path pool) instead of render_kernel
   uint32_t num_cus = 0;
   // scratch owned by the scene: stats, work counter, host-render framebuffer
   DeviceStats* d_stats = nullptr;
@@ -226,11 +228,17 @@ struct LaunchCfg {
 
 using RenderKernel = void (*)(const DScene, const RenderArgs, float*, DeviceStats*, unsigned int*);
 RenderKernel pick_kernel(const VimgDeviceScene* s) {
+  if (s->pooled) {
+    if (s->textured)
+      return s->waves_per_simd >= 3 ? render_pool_kernel<true, 3> : render_pool_kernel<true, 2>;
+    return s->waves_per_simd >= 3 ? render_pool_kernel<false, 3> : render_pool_kernel<false, 2>;
+  }
   if (s->textured) return s->waves_per_simd >= 3 ? render_kernel<true, 3> : render_kernel<true, 2>;
   return s->waves_per_simd >= 3 ? render_kernel<false, 3> : render_kernel<false, 2>;
 }
 
-LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int sx, int sy) {
+LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int sx, int sy,
+                      bool for_render = true) {
   LaunchCfg c{};
   RenderArgs& a = c.args;
   a.integrator = p->integrator;
@@ -253,6 +261,23 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   if (stack_bytes + 512 < budget) nodes = (budget - stack_bytes - 256) / 56u;
   a.lds_nodes = std::min(nodes, s->d.num_nodes);
   c.lds_bytes = ((a.lds_nodes * 56u + 255u) & ~255u) + stack_bytes;
+  a.pool_slots = 0;
+  a.pool_refill = 16;
+  a.pool_vbatch = 48;
+  a.pool_classes = 2;
+  if (const char* e = getenv("VIMG_HIP_POOL_VBATCH")) a.pool_vbatch = uint32_t(std::min(64, std::max(1, atoi(e))));
+  if (const char* e = getenv("VIMG_HIP_POOL_CLASSES")) a.pool_classes = uint32_t(std::min(3, std::max(1, atoi(e))));
+  if (s->pooled && for_render) {
+    // the pool takes what is left of this workgroup's share of the CU's 160 KiB
+    const uint32_t share = (160u * 1024u) / uint32_t(s->waves_per_simd) - 1024u;
+    const uint32_t per_slot = (SR_COUNT * 4u + 4u) * 4u * 4u;   // bytes per slot, all four waves
+    uint32_t slots = share > c.lds_bytes ? (share - c.lds_bytes) / per_slot : 0;
+    slots = std::min(slots, 256u);
+    if (const char* e = getenv("VIMG_HIP_POOL_SLOTS")) slots = std::min(slots, uint32_t(atoi(e)));
+    if (const char* e = getenv("VIMG_HIP_POOL_REFILL")) a.pool_refill = uint32_t(std::max(1, atoi(e)));
+    a.pool_slots = std::max(slots, 8u);
+    c.lds_bytes += a.pool_slots * per_slot;
+  }
   // persistent grid: as many 4-wave workgroups as the kernel's registers and LDS let a CU hold
   // (asked of the runtime), never more than the work
   int per_cu = 0;
@@ -305,6 +330,17 @@ int fetch_stats(VimgDeviceScene* s, const VimgRenderParams* p, VimgRenderStats* 
     std::fprintf(stderr, "[vimg diag] wave trips: descend %llu (lane visits %llu, util %.3f)  prim %llu (lane tests %llu, util %.3f)  main-loop iterations %llu\n",
                  ds.trip_descend, ds.internal, ds.trip_descend ? double(ds.internal) / (64.0 * ds.trip_descend) : 0.0,
                  ds.trip_prim, ds.prim, ds.trip_prim ? double(ds.prim) / (64.0 * ds.trip_prim) : 0.0, ds.iterations);
+#ifdef VIMG_PROFILE
+  if (getenv("VIMG_HIP_DIAG") && ds.prof[PF_TOTAL]) {
+    static const char* names[PF_COUNT] = {"total", "v_load+logic+hit_info", "v_light_sample", "v_bsdf_sample",
+                                          "v_bsdf_eval_x2", "v_finish+regen", "v_store", "w_refill+setup",
+                                          "w_box_loop", "w_leaf_loop", "w_retire", "v_batches", "v_lanes",
+                                          "v_at_vertex", "w_rounds"};
+    for (int k = 0; k < PF_COUNT; ++k)
+      std::fprintf(stderr, "[vimg prof] %-24s %14llu  %6.2f %%\n", names[k], ds.prof[k],
+                   100.0 * double(ds.prof[k]) / double(ds.prof[PF_TOTAL]));
+  }
+#endif
   return VIMG_OK;
 }
 
@@ -507,6 +543,17 @@ int vimg_hip_scene_upload(const VimgScene* sc, VimgDeviceScene** out) {
   UP(nodes, nodes.data(), nodes.size());
   UP(leaf_prims, leaf.data(), leaf.size());
   UP(prims, sc->prims, sc->num_prims);
+  {
+    std::vector<uint32_t> cls(sc->num_prims, 0);
+    for (uint32_t i = 0; i < sc->num_prims; ++i) {
+      const VimgPrim& pr = sc->prims[i];
+      const uint32_t mat = pr.type == VIMG_PRIM_TRIANGLE ? sc->meshes[sc->tri_mesh[pr.index]].material
+                                                         : sc->spheres[pr.index].material;
+      const uint32_t t = sc->materials[mat].type;
+      cls[i] = t == VIMG_MAT_LAMBERTIAN ? 1u : (t == VIMG_MAT_PRINCIPLED ? 2u : 0u);
+    }
+    UP(prim_class, cls.data(), cls.size());
+  }
   UP(tri_shade, shade.data(), shade.size());
   UP(tri_area_pdf, area_pdf.data(), area_pdf.size());
   UP(meshes, sc->meshes, sc->num_meshes);
@@ -533,6 +580,13 @@ int vimg_hip_scene_upload(const VimgScene* sc, VimgDeviceScene** out) {
   // SIMD; small scenes are VALU-bound and want the build that spills least
   s->waves_per_simd = (s->total_bytes > (32u << 20)) ? 3 : 2;
   if (const char* e = getenv("VIMG_HIP_WAVES_PER_SIMD")) s->waves_per_simd = atoi(e);
+  // which kernel: the pooled variant (paths decoupled from lanes through an LDS pool) wins where
+  // the scene is on chip and the walk is short, i.e. VALU-bound work (config 2: +8.5 %); its LDS
+  // pool costs occupancy, which is what the large, latency-bound scenes need (config 4/5: 2x
+  // slower), and the textured build's bigger slot state loses the gain (config 3: -6 %)
+  s->pooled = !s->textured && s->total_bytes <= (32u << 20);
+  if (const char* e = getenv("VIMG_HIP_POOL")) s->pooled = atoi(e) != 0;
+  if (cam.res_x > 65535 || cam.res_y > 65535) s->pooled = false;   // slots pack pixel coordinates
   hipDeviceProp_t prop{};
   if (hipGetDeviceProperties(&prop, g_device) != hipSuccess) return bail(fail(VIMG_E_DEVICE, "hipGetDeviceProperties failed"));
   s->num_cus = static_cast<uint32_t>(prop.multiProcessorCount);
@@ -649,6 +703,9 @@ int vimg_hip_time_renders(VimgDeviceScene* s, const VimgRenderParams* p, void* d
     // the counter reset is part of a launch's prologue; the events bracket the kernel only
     HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(unsigned int), g_stream));
     LaunchCfg c = make_launch(s, p, -1, -1);
+    if (c.lds_bytes > 48u * 1024u)
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(s)),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(c.lds_bytes)));
     HIP_TRY(hipEventRecord(ev[2 * i], g_stream));
     hipLaunchKernelGGL(pick_kernel(s), dim3(c.grid), dim3(256), c.lds_bytes, g_stream, s->d, c.args,
                        static_cast<float*>(d_out), static_cast<DeviceStats*>(nullptr), s->d_counter);
@@ -695,7 +752,7 @@ int vimg_hip_probe(VimgDeviceScene* s, int kind, int n, const float* in_host, fl
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), size_t(n) * n_out[kind] * sizeof(float)));
   HIP_TRY(hipMemcpy(d_in, in_host, size_t(n) * n_in[kind] * sizeof(float), hipMemcpyHostToDevice));
   VimgRenderParams p{VIMG_INTEGRATOR_MIS, 1, 1, 0, 1};
-  LaunchCfg c = make_launch(s, &p, -1, -1);
+  LaunchCfg c = make_launch(s, &p, -1, -1, false);
   const uint32_t grid = (uint32_t(n) + 255) / 256;
   if (s->textured)
     hipLaunchKernelGGL(probe_kernel<true>, dim3(grid), dim3(256), c.lds_bytes, g_stream, s->d, c.args,
