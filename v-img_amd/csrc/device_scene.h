@@ -48,7 +48,7 @@ struct __attribute__((aligned(16))) DLeafPrim {
   float c0;
   uint32_t prim;   // index into the reference's list_objects order
   uint32_t kind;
-  uint32_t pad;
+  uint32_t cls;    // material class of the primitive: 0 emitter, 1 Lambertian, 2 Principled, 3 other
 };
 static_assert(sizeof(DLeafPrim) == 48, "DLeafPrim must be 48 bytes");
 
@@ -80,7 +80,6 @@ struct DScene {
 
   // primitives / shading data
   gptr<VimgPrim> prims;
-  gptr<uint32_t> prim_class;   // per primitive: 1 Lambertian, 2 Principled, 0 anything else
   gptr<DTriShade> tri_shade;
   gptr<float> tri_area_pdf;   // 1 / (|cross(e2, e1)| / 2) per triangle (triangle.cpp:229-231,246)
   gptr<VimgMesh> meshes;
@@ -116,7 +115,8 @@ struct RenderArgs {
   uint32_t pool_slots;              // pooled kernel: path slots per wave (0 = lane-bound kernel)
   uint32_t pool_refill;             // pooled kernel: finished rays that trigger a refill pass
   uint32_t pool_vbatch;             // pooled kernel: queued slots of one class that start a vertex batch
-  uint32_t pool_classes;            // pooled kernel: 1 = one vertex queue, 2 = Principled apart, 3 = + Lambertian apart
+  uint32_t pool_starve;             // pooled kernel: idle walk lanes (with no ray queued) that force a partial vertex batch
+  uint32_t pool_classes;            // pooled kernel: vertex queues: 1 = one, 2 = Principled apart, 3 = + Lambertian apart
   int32_t single_x, single_y;       // trace_pixel mode when >= 0
 };
 

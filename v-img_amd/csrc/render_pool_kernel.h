@@ -9,9 +9,12 @@
 //   * two wave-private queues hold slot ids: Q_walk (rays ready to be walked) and Q_vertex (walks
 //     finished, or a new path needed).  The queues are used by one wave only, so pushing and
 //     popping is __ballot/popcount arithmetic on wave-uniform counters — no atomics, no waiting;
-//   * the VERTEX stage always runs on a full batch of 64 slots (NEE result, emitter / miss /
-//     roulette logic, hit record, light sample, BSDF sample, both BSDF evaluations, or the next
-//     camera ray of a finished path);
+//   * the VERTEX stage runs on batches of up to 64 slots of ONE class, known when the walk ends from
+//     the flags and the material class baked into the leaf record: class 0 = "finishers" (miss,
+//     emitter hit, failed BSDF sample, roulette death: NEE result, emitter / miss MIS weight, pixel
+//     accumulation, next camera ray), classes 1-3 = path vertices by material (hit record,
+//     roulette, light sample, BSDF sample, both BSDF evaluations).  A path that ends inside a
+//     vertex batch is handed to the finisher queue, so every stage runs with its lanes full;
 //   * the WALK stage is a persistent while-while loop whose lanes refill from Q_walk the moment
 //     their ray is done (shadow ray first, then the path ray of the same vertex), so the box loop
 //     and the primitive loop keep their lanes busy.
@@ -72,19 +75,20 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
   constexpr uint32_t roulette_threshold = 5;
   const bool material_mode = (A.integrator == VIMG_INTEGRATOR_MATERIAL);
   const uint32_t P = A.pool_slots;
+  constexpr uint32_t NREC = TEX ? SR_COUNT : SR_COUNT - 1u;   // SR_CONE (last) only in the textured build
 
   // LDS carve-out of this wave behind the node planes and the four traversal stacks
   VIMG_LDS uint32_t* pool;
   VIMG_LDS uint32_t* q_walk;
-  VIMG_LDS uint32_t* q_vertex;   // three rings of capacity P: class 0 (other), 1 (Lambertian), 2 (Principled)
+  VIMG_LDS uint32_t* q_vertex;   // four rings of capacity P: class 0 finishers, 1 Lambertian (+rest), 2 Principled, 3 other
   {
     const uint32_t node_bytes = (lds_node_bytes(A.lds_nodes) + 255u) & ~255u;
     const uint32_t stack_bytes = 4u * A.stack_entries * 64u * 4u;
-    const uint32_t per_wave = (SR_COUNT * 4u + 4u) * P;
+    const uint32_t per_wave = (NREC * 4u + 5u) * P;
     VIMG_LDS uint32_t* base =
         reinterpret_cast<VIMG_LDS uint32_t*>((VIMG_LDS unsigned char*)lds_raw + node_bytes + stack_bytes);
     pool = base + wave * per_wave;
-    q_walk = pool + SR_COUNT * 4u * P;
+    q_walk = pool + NREC * 4u * P;
     q_vertex = q_walk + P;
   }
   VIMG_LDS v4u* recs = reinterpret_cast<VIMG_LDS v4u*>(pool);
@@ -102,7 +106,8 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
 
   // wave-uniform queue state (rings of capacity P)
   uint32_t qw_head = 0, qw_count = 0;
-  uint32_t qv_head0 = 0, qv_head1 = 0, qv_head2 = 0, qv_count0 = 0, qv_count1 = 0, qv_count2 = 0;
+  uint32_t qv_head0 = 0, qv_head1 = 0, qv_head2 = 0, qv_head3 = 0;
+  uint32_t qv_count0 = 0, qv_count1 = 0, qv_count2 = 0, qv_count3 = 0;
   auto ring = [&](uint32_t i) { return i >= P ? i - P : i; };
 
   // every slot starts "fresh": it needs a pixel
@@ -114,7 +119,7 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
   bool pixels_left = true;   // wave-uniform: the global counter still had work last time
 
   // ---- persistent walk registers of the lane
-  uint32_t w_slot = SLOT_IDLE, w_phase = 0, w_flags = 0;
+  uint32_t w_slot = SLOT_IDLE, w_phase = 0, w_flags = 0, w_cls = 0;
   bool w_setup = false, w_any = false, w_found = false, w_exact = false;
   TravRay ray{f3{0.f, 0.f, 0.f}, f3{0.f, 0.f, 1.f}, 0.0001f, VIMG_INF};
   f3 w_inv{1.f, 1.f, 1.f};
@@ -127,28 +132,35 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
   rec.e0 = rec.e1 = rec.e2 = rec.inv_det = 0.f;
 
   for (;;) {
-    const bool inflight = __any(w_slot != SLOT_IDLE);
+    const uint32_t n_walking = __popcll(__ballot(w_slot != SLOT_IDLE));
+    const bool inflight = n_walking != 0u;
     // vertex batches are sorted by the material class of the hit (known from the primitive at the
     // end of the walk), so that a batch executes one material's code: a full batch of any class
     // runs at once; when the walkers have nothing left, the fullest class runs partially filled
-    const uint32_t qv_max = qv_count0 > qv_count1 ? (qv_count0 > qv_count2 ? qv_count0 : qv_count2)
-                                                  : (qv_count1 > qv_count2 ? qv_count1 : qv_count2);
-    const bool run_vertex = (qv_max >= A.pool_vbatch) || (qv_max > 0u && qw_count == 0u && !inflight);
+    const uint32_t qv_max01 = qv_count0 > qv_count1 ? qv_count0 : qv_count1;
+    const uint32_t qv_max23 = qv_count2 > qv_count3 ? qv_count2 : qv_count3;
+    const uint32_t qv_max = qv_max01 > qv_max23 ? qv_max01 : qv_max23;
+    // a vertex batch runs when one is full, or when the walkers starve: no queued ray and
+    // pool_starve or more idle lanes (the walk would go on half empty while slots wait here)
+    const bool run_vertex = (qv_max >= A.pool_vbatch) ||
+                            (qv_max > 0u && qw_count == 0u && 64u - n_walking >= A.pool_starve);
     if (!run_vertex && qw_count == 0u && !inflight) break;   // every queue is empty: all done
     if (full_stats && lane == 0) iter_wave++;
 
     if (run_vertex) {
       // ================================================================== VERTEX stage
       PROF_LAP(PF_W_RETIRE)
-      const uint32_t cls = (qv_count0 == qv_max) ? 0u : (qv_count1 == qv_max ? 1u : 2u);
-      const uint32_t qv_count = cls == 0 ? qv_count0 : (cls == 1 ? qv_count1 : qv_count2);
-      const uint32_t qv_head = cls == 0 ? qv_head0 : (cls == 1 ? qv_head1 : qv_head2);
+      const uint32_t cls = (qv_count0 == qv_max) ? 0u : (qv_count1 == qv_max ? 1u : (qv_count2 == qv_max ? 2u : 3u));
+      const uint32_t qv_count = cls == 0 ? qv_count0 : (cls == 1 ? qv_count1 : (cls == 2 ? qv_count2 : qv_count3));
+      const uint32_t qv_head = cls == 0 ? qv_head0 : (cls == 1 ? qv_head1 : (cls == 2 ? qv_head2 : qv_head3));
+      const bool finisher_batch = (cls == 0);
       const uint32_t n = qv_count < 64u ? qv_count : 64u;
       const bool on = lane < n;
       const uint32_t slot = on ? q_vertex[cls * P + ring(qv_head + lane)] : 0u;
       if (cls == 0) { qv_head0 = ring(qv_head0 + n); qv_count0 -= n; }
       else if (cls == 1) { qv_head1 = ring(qv_head1 + n); qv_count1 -= n; }
-      else { qv_head2 = ring(qv_head2 + n); qv_count2 -= n; }
+      else if (cls == 2) { qv_head2 = ring(qv_head2 + n); qv_count2 -= n; }
+      else { qv_head3 = ring(qv_head3 + n); qv_count3 -= n; }
 
       const v4u r_ray = on ? rd(SR_RAY, slot) : v4u{0u, 0u, 0u, 0u};
       uint32_t flags = r_ray.w;
@@ -432,6 +444,12 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
       // ---- finished samples: accumulate, pixel write-back, next pixel, next camera ray
       bool need_pixel = fresh;
       bool retire = false;
+      if (!finisher_batch) {
+        // a path that ended at this vertex (roulette, depth limit, no ray left) is accumulated by
+        // the finisher stage: it travels there with neither ray set, which that stage reads as
+        // "return bounce_result" (the !SF_HAS_R branch above)
+        if (finish) has_s = false, has_r = false;
+      } else {
       if (finish) {
         if (is_nan(result.x) || is_nan(result.y) || is_nan(result.z)) nan_samples++;
         acc = acc + result;
@@ -507,6 +525,7 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
         has_s = false;
         has_r = true;
       }
+      }   // finisher_batch
 
       PROF_LAP(PF_V_FINISH)
       // ---- registers -> slot state, slot -> Q_walk
@@ -527,9 +546,12 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
         if constexpr (TEX) wr(SR_CONE, slot, v4u{fu(cone.cone_width), fu(cone.spread_angle), 0u, 0u});
       }
       {
-        const unsigned long long mask = __ballot(keep);
-        if (keep) q_walk[ring(qw_head + qw_count + lane_rank(mask, lane))] = slot;
+        const bool to_walk = keep && (has_s || has_r), to_fin = keep && !to_walk;
+        const unsigned long long mask = __ballot(to_walk), mfin = __ballot(to_fin);
+        if (to_walk) q_walk[ring(qw_head + qw_count + lane_rank(mask, lane))] = slot;
+        if (to_fin) q_vertex[ring(qv_head0 + qv_count0 + lane_rank(mfin, lane))] = slot;
         qw_count += __popcll(mask);
+        qv_count0 += __popcll(mfin);
       }
       PROF_LAP(PF_V_STORE)
     } else {
@@ -663,6 +685,7 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
                   rec.e0 = e0, rec.e1 = e1, rec.e2 = e2, rec.inv_det = idet;
                   rec.prim = lp->prim;
                   rec.kind = kind;
+                  w_cls = lp->cls;
                 }
               }
             }
@@ -703,30 +726,44 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
           if (done_item) word(SR_RAY, 3, w_slot) = w_flags;
         }
         {
-          // material class of the vertex this slot arrives at (0 when there is none)
+          // class of the batch this slot joins: 0 = its path ends (miss, no path ray, emitter hit under
+          // mis, any hit under the normal integrators), else the material class of the vertex
+          // (leaf record: 0 emitter, 1 Lambertian, 2 Principled, 3 other)
           uint32_t cls = 0;
           if (done_item && (w_flags & SF_FOUND) && A.integrator >= VIMG_INTEGRATOR_MATERIAL) {
-            cls = g.prim_class[rec.prim];
-            if (A.pool_classes == 1) cls = 0;
-            else if (A.pool_classes == 2) cls = (cls == 2) ? 2u : 0u;
+            cls = w_cls;
+            if (cls == 0 && material_mode) cls = 3;   // material_integrator shades emitters too
+            if (cls != 0) {
+              if (A.pool_classes == 1) cls = 1;
+              else if (A.pool_classes == 2) cls = (cls == 2) ? 2u : 1u;
+            }
           }
           const unsigned long long m0 = __ballot(done_item && cls == 0),
                                    m1 = __ballot(done_item && cls == 1),
-                                   m2 = __ballot(done_item && cls == 2);
+                                   m2 = __ballot(done_item && cls == 2),
+                                   m3 = __ballot(done_item && cls == 3);
           if (done_item) {
             if (cls == 0) q_vertex[ring(qv_head0 + qv_count0 + lane_rank(m0, lane))] = w_slot;
             else if (cls == 1) q_vertex[P + ring(qv_head1 + qv_count1 + lane_rank(m1, lane))] = w_slot;
-            else q_vertex[2 * P + ring(qv_head2 + qv_count2 + lane_rank(m2, lane))] = w_slot;
+            else if (cls == 2) q_vertex[2 * P + ring(qv_head2 + qv_count2 + lane_rank(m2, lane))] = w_slot;
+            else q_vertex[3 * P + ring(qv_head3 + qv_count3 + lane_rank(m3, lane))] = w_slot;
             w_slot = SLOT_IDLE;
           }
           qv_count0 += __popcll(m0);
           qv_count1 += __popcll(m1);
           qv_count2 += __popcll(m2);
+          qv_count3 += __popcll(m3);
         }
         PROF_LAP(PF_W_RETIRE)
         // (5) leave when a full vertex batch waits, or when nothing is left to walk
-        if (qv_count0 >= A.pool_vbatch || qv_count1 >= A.pool_vbatch || qv_count2 >= A.pool_vbatch) break;
-        if (qw_count == 0u && !__any(w_slot != SLOT_IDLE)) break;
+        if (qv_count0 >= A.pool_vbatch || qv_count1 >= A.pool_vbatch || qv_count2 >= A.pool_vbatch ||
+            qv_count3 >= A.pool_vbatch)
+          break;
+        if (qw_count == 0u) {
+          const uint32_t walking = __popcll(__ballot(w_slot != SLOT_IDLE));
+          if (walking == 0u) break;
+          if (64u - walking >= A.pool_starve && (qv_count0 | qv_count1 | qv_count2 | qv_count3) != 0u) break;
+        }
       }
     }
   }

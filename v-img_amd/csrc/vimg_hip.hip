@@ -265,12 +265,15 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   a.pool_refill = 16;
   a.pool_vbatch = 48;
   a.pool_classes = 2;
+  a.pool_starve = 24;
+  if (const char* e = getenv("VIMG_HIP_POOL_STARVE")) a.pool_starve = uint32_t(std::min(64, std::max(1, atoi(e))));
   if (const char* e = getenv("VIMG_HIP_POOL_VBATCH")) a.pool_vbatch = uint32_t(std::min(64, std::max(1, atoi(e))));
   if (const char* e = getenv("VIMG_HIP_POOL_CLASSES")) a.pool_classes = uint32_t(std::min(3, std::max(1, atoi(e))));
   if (s->pooled && for_render) {
     // the pool takes what is left of this workgroup's share of the CU's 160 KiB
     const uint32_t share = (160u * 1024u) / uint32_t(s->waves_per_simd) - 1024u;
-    const uint32_t per_slot = (SR_COUNT * 4u + 4u) * 4u * 4u;   // bytes per slot, all four waves
+    const uint32_t nrec = s->textured ? SR_COUNT : SR_COUNT - 1u;
+    const uint32_t per_slot = (nrec * 4u + 5u) * 4u * 4u;   // bytes per slot, all four waves
     uint32_t slots = share > c.lds_bytes ? (share - c.lds_bytes) / per_slot : 0;
     slots = std::min(slots, 256u);
     if (const char* e = getenv("VIMG_HIP_POOL_SLOTS")) slots = std::min(slots, uint32_t(atoi(e)));
@@ -494,6 +497,12 @@ int vimg_hip_scene_upload(const VimgScene* sc, VimgDeviceScene** out) {
     const VimgPrim& p = sc->prims[prim];
     DLeafPrim lp{};
     lp.prim = prim;
+    {
+      const uint32_t mat = p.type == VIMG_PRIM_TRIANGLE ? sc->meshes[sc->tri_mesh[p.index]].material
+                                                        : sc->spheres[p.index].material;
+      const uint32_t t = sc->materials[mat].type;
+      lp.cls = t == VIMG_MAT_DIFFUSE_LIGHT ? 0u : t == VIMG_MAT_LAMBERTIAN ? 1u : t == VIMG_MAT_PRINCIPLED ? 2u : 3u;
+    }
     if (p.type == VIMG_PRIM_TRIANGLE) {
       const float* v = shade[p.index].p;
       lp.a = v4f{v[0], v[1], v[2], v[3]};
@@ -543,17 +552,6 @@ int vimg_hip_scene_upload(const VimgScene* sc, VimgDeviceScene** out) {
   UP(nodes, nodes.data(), nodes.size());
   UP(leaf_prims, leaf.data(), leaf.size());
   UP(prims, sc->prims, sc->num_prims);
-  {
-    std::vector<uint32_t> cls(sc->num_prims, 0);
-    for (uint32_t i = 0; i < sc->num_prims; ++i) {
-      const VimgPrim& pr = sc->prims[i];
-      const uint32_t mat = pr.type == VIMG_PRIM_TRIANGLE ? sc->meshes[sc->tri_mesh[pr.index]].material
-                                                         : sc->spheres[pr.index].material;
-      const uint32_t t = sc->materials[mat].type;
-      cls[i] = t == VIMG_MAT_LAMBERTIAN ? 1u : (t == VIMG_MAT_PRINCIPLED ? 2u : 0u);
-    }
-    UP(prim_class, cls.data(), cls.size());
-  }
   UP(tri_shade, shade.data(), shade.size());
   UP(tri_area_pdf, area_pdf.data(), area_pdf.size());
   UP(meshes, sc->meshes, sc->num_meshes);
