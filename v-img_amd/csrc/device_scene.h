@@ -26,6 +26,7 @@ using gptr = const VIMG_GLOBAL T*;
 // builtin vector types (unlike HIP's float4 class) can be loaded from any address space
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
 // One INTERNAL BVH node, 64 B: the boxes of both children exactly as BB_mins_maxes[2c+2 .. 2c+5]
 // holds them (reference include/bvh.h:171-188) and a reference to each child.  A child
@@ -112,6 +113,7 @@ struct RenderArgs {
   uint32_t full_stats;
   uint32_t stack_entries;           // per-lane LDS stack depth (max_depth + 2)
   uint32_t lds_nodes;               // number of top-of-tree nodes staged into LDS
+  VIMG_GLOBAL v4u* pool_cold;       // pooled kernel: cold slot records, [wave][slot][record] (scene-owned scratch)
   uint32_t pool_slots;              // pooled kernel: path slots per wave (0 = lane-bound kernel)
   uint32_t pool_refill;             // pooled kernel: finished rays that trigger a refill pass
   uint32_t pool_vbatch;             // pooled kernel: queued slots of one class that start a vertex batch

@@ -56,6 +56,8 @@ struct VimgDeviceScene {
   DeviceStats* d_stats = nullptr;
   unsigned int* d_counter = nullptr;
   float* d_frame = nullptr;
+  void* d_pool_cold = nullptr;   // pooled kernel: cold slot records of every resident wave
+  size_t pool_cold_bytes = 0;
   size_t frame_floats = 0;
 };
 
@@ -263,8 +265,8 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   c.lds_bytes = ((a.lds_nodes * 56u + 255u) & ~255u) + stack_bytes;
   a.pool_slots = 0;
   a.pool_refill = 16;
-  a.pool_vbatch = 48;
-  a.pool_classes = 2;
+  a.pool_vbatch = 64;
+  a.pool_classes = 3;
   a.pool_starve = 24;
   if (const char* e = getenv("VIMG_HIP_POOL_STARVE")) a.pool_starve = uint32_t(std::min(64, std::max(1, atoi(e))));
   if (const char* e = getenv("VIMG_HIP_POOL_VBATCH")) a.pool_vbatch = uint32_t(std::min(64, std::max(1, atoi(e))));
@@ -272,8 +274,7 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   if (s->pooled && for_render) {
     // the pool takes what is left of this workgroup's share of the CU's 160 KiB
     const uint32_t share = (160u * 1024u) / uint32_t(s->waves_per_simd) - 1024u;
-    const uint32_t nrec = s->textured ? SR_COUNT : SR_COUNT - 1u;
-    const uint32_t per_slot = (nrec * 4u + 5u) * 4u * 4u;   // bytes per slot, all four waves
+    const uint32_t per_slot = POOL_LDS_WORDS * 4u * 4u;   // LDS bytes per slot, all four waves
     uint32_t slots = share > c.lds_bytes ? (share - c.lds_bytes) / per_slot : 0;
     slots = std::min(slots, 256u);
     if (const char* e = getenv("VIMG_HIP_POOL_SLOTS")) slots = std::min(slots, uint32_t(atoi(e)));
@@ -293,9 +294,28 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   return c;
 }
 
+// The pooled kernel keeps the cold records of its path slots in global memory: one region per
+// resident wave, owned by the scene and grown on demand (42 MB for config 2 on 256 CUs).
+int ensure_pool(VimgDeviceScene* s, LaunchCfg& c) {
+  c.args.pool_cold = nullptr;
+  if (!s->pooled || c.args.pool_slots == 0) return VIMG_OK;
+  const size_t ncold = s->textured ? SC_COUNT : SC_COUNT - 1u;
+  const size_t need = size_t(c.grid) * 4u * ncold * c.args.pool_slots * 16u;
+  if (need > s->pool_cold_bytes) {
+    if (s->d_pool_cold) HIP_TRY(hipFree(s->d_pool_cold));
+    s->d_pool_cold = nullptr;
+    s->pool_cold_bytes = 0;
+    HIP_TRY(hipMalloc(&s->d_pool_cold, need));
+    s->pool_cold_bytes = need;
+  }
+  c.args.pool_cold = (VIMG_GLOBAL v4u*)s->d_pool_cold;
+  return VIMG_OK;
+}
+
 int launch_render(VimgDeviceScene* s, const VimgRenderParams* p, float* d_out, hipStream_t st,
                   bool full_stats, bool want_stats, int sx, int sy) {
   LaunchCfg c = make_launch(s, p, sx, sy);
+  if (int rc = ensure_pool(s, c)) return rc;
   c.args.full_stats = full_stats ? 1u : 0u;
   if (c.args.num_local_tiles == 0 && sx < 0) return VIMG_OK;
   HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(unsigned int), st));
@@ -601,6 +621,7 @@ int vimg_hip_scene_free(VimgDeviceScene* s) {
   if (s->d_stats) (void)hipFree(s->d_stats);
   if (s->d_counter) (void)hipFree(s->d_counter);
   if (s->d_frame) (void)hipFree(s->d_frame);
+  if (s->d_pool_cold) (void)hipFree(s->d_pool_cold);
   delete s;
   return VIMG_OK;
 }
@@ -701,6 +722,7 @@ int vimg_hip_time_renders(VimgDeviceScene* s, const VimgRenderParams* p, void* d
     // the counter reset is part of a launch's prologue; the events bracket the kernel only
     HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(unsigned int), g_stream));
     LaunchCfg c = make_launch(s, p, -1, -1);
+    if (int rc = ensure_pool(s, c)) return rc;
     if (c.lds_bytes > 48u * 1024u)
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(s)),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(c.lds_bytes)));
