@@ -114,6 +114,7 @@ struct RenderArgs {
   uint32_t stack_entries;           // per-lane LDS stack depth (max_depth + 2)
   uint32_t lds_nodes;               // number of top-of-tree nodes staged into LDS
   VIMG_GLOBAL v4u* pool_cold;       // pooled kernel: cold slot records, [wave][slot][record] (scene-owned scratch)
+  uint32_t lds_leaf;                // pooled kernel: number of leaf records copied to LDS (all or 0)
   uint32_t pool_slots;              // pooled kernel: path slots per wave (0 = lane-bound kernel)
   uint32_t pool_refill;             // pooled kernel: finished rays that trigger a refill pass
   uint32_t pool_vbatch;             // pooled kernel: queued slots of one class that start a vertex batch
@@ -127,10 +128,11 @@ struct DeviceStats {
   unsigned long long trip_descend, trip_prim, iterations;   // wave-level loop trips (diagnostic)
   // -DVIMG_PROFILE builds only (make prof): s_memtime cycles of wave 0.. summed over waves, per
   // stage of render_pool_kernel, and lanes switched on per vertex batch
-  unsigned long long prof[16];
+  unsigned long long prof[24];
 };
 enum : int { PF_TOTAL = 0, PF_V_LOAD, PF_V_LIGHT, PF_V_SAMPLE, PF_V_EVAL, PF_V_FINISH, PF_V_STORE,
              PF_W_REFILL, PF_W_BOX, PF_W_LEAF, PF_W_RETIRE, PF_V_BATCHES, PF_V_LANES, PF_V_ATVERTEX,
-             PF_W_ROUNDS, PF_COUNT };
+             PF_W_ROUNDS, PF_CLS_CYC0, PF_CLS_CYC1, PF_CLS_CYC2, PF_CLS_CYC3, PF_CLS_LANES0, PF_CLS_LANES1,
+             PF_CLS_LANES2, PF_CLS_LANES3, PF_COUNT };
 
 }  // namespace vimg

@@ -60,7 +60,9 @@ constexpr uint32_t SLOT_IDLE = 0xffffffffu;
 #define PROF_DECL unsigned long long prof_acc[PF_COUNT] = {}; unsigned long long prof_t = __builtin_readcyclecounter(); const unsigned long long prof_t0 = prof_t;
 #define PROF_LAP(k) { const unsigned long long now_ = __builtin_readcyclecounter(); prof_acc[k] += now_ - prof_t; prof_t = now_; }
 #define PROF_ADD(k, v) { prof_acc[k] += (v); }
+#define PROF_NOW() __builtin_readcyclecounter()
 #else
+#define PROF_NOW() 0ull
 #define PROF_DECL
 #define PROF_LAP(k)
 #define PROF_ADD(k, v)
@@ -94,6 +96,7 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
   // LDS carve-out of this wave behind the node planes and the four traversal stacks
   VIMG_LDS uint32_t* pool;
   VIMG_LDS uint32_t* q_walk;
+  VIMG_LDS v4f* lds_leaf;        // copy of leaf_prims (all of them) when A.lds_leaf != 0
   VIMG_LDS uint32_t* q_prim;     // primitive id of the hit, per slot
   VIMG_LDS uint32_t* q_vertex;   // four rings of capacity P: class 0 finishers, 1 Lambertian (+rest), 2 Principled, 3 other
   {
@@ -106,7 +109,14 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
     q_walk = pool + SR_COUNT * 4u * P;
     q_prim = q_walk + P;
     q_vertex = q_prim + P;
+    // small scenes: the leaf records behind the four pools (an LDS read instead of an L1 hit per
+    // primitive test; the walk is a chain of dependent loads at two waves per SIMD)
+    lds_leaf = reinterpret_cast<VIMG_LDS v4f*>(base + 4u * per_wave);
+    for (uint32_t i = threadIdx.x; i < A.lds_leaf * 3u; i += blockDim.x)
+      lds_leaf[i] = reinterpret_cast<gptr<v4f>>(g.leaf_prims)[i];
+    if (A.lds_leaf) __syncthreads();
   }
+  const bool leaf_in_lds = A.lds_leaf != 0u;
   VIMG_LDS v4u* recs = reinterpret_cast<VIMG_LDS v4u*>(pool);
   auto rd = [&](uint32_t r, uint32_t slot) -> v4u { return recs[r * P + slot]; };
   auto wr = [&](uint32_t r, uint32_t slot, v4u v) { recs[r * P + slot] = v; };
@@ -166,6 +176,7 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
     if (run_vertex) {
       // ================================================================== VERTEX stage
       PROF_LAP(PF_W_RETIRE)
+      [[maybe_unused]] const unsigned long long prof_v0 = PROF_NOW();
       const uint32_t cls = (qv_count0 == qv_max) ? 0u : (qv_count1 == qv_max ? 1u : (qv_count2 == qv_max ? 2u : 3u));
       const uint32_t qv_count = cls == 0 ? qv_count0 : (cls == 1 ? qv_count1 : (cls == 2 ? qv_count2 : qv_count3));
       const uint32_t qv_head = cls == 0 ? qv_head0 : (cls == 1 ? qv_head1 : (cls == 2 ? qv_head2 : qv_head3));
@@ -575,6 +586,7 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
         qv_count0 += __popcll(mfin);
       }
       PROF_LAP(PF_V_STORE)
+      PROF_ADD(PF_CLS_CYC0 + cls, PROF_NOW() - prof_v0) PROF_ADD(PF_CLS_LANES0 + cls, n)
     } else {
       // ================================================================== WALK stage
       PROF_LAP(PF_W_RETIRE)
@@ -681,9 +693,17 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
             bool stop = false;
             for (uint32_t i = 0; i < count && !stop; ++i) {
               gptr<DLeafPrim> lp = g.leaf_prims + (first + i);
-              const v4f a = lp->a, b = lp->b;
-              const float c0 = lp->c0;
-              const uint32_t kind = lp->kind;
+              v4f a, b, c;
+              if (leaf_in_lds) {
+                const VIMG_LDS v4f* ll = lds_leaf + (first + i) * 3u;
+                a = ll[0], b = ll[1], c = ll[2];
+              } else {
+                a = lp->a, b = lp->b;
+                c = reinterpret_cast<gptr<v4f>>(lp)[2];
+              }
+              const float c0 = c.x;
+              const uint32_t lp_prim = __float_as_uint(c.y), kind = __float_as_uint(c.z),
+                             lp_cls = __float_as_uint(c.w);   // DLeafPrim: c0 | prim | kind | cls
               if (full_stats) {
                 cnt.prim++;
                 if (first_active_lane()) cnt.trip_prim++;
@@ -704,9 +724,9 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
                   stop = true;   // exit on first hit
                 } else {
                   rec.e0 = e0, rec.e1 = e1, rec.e2 = e2, rec.inv_det = idet;
-                  rec.prim = lp->prim;
+                  rec.prim = lp_prim;
                   rec.kind = kind;
-                  w_cls = lp->cls;
+                  w_cls = lp_cls;
                 }
               }
             }

@@ -52,6 +52,7 @@ struct VimgDeviceScene {
   int waves_per_simd = 2;      // which register-budget build of the kernel to launch
   bool pooled = false;         // render_pool_kernel (LDS path pool) instead of render_kernel
   uint32_t num_cus = 0;
+  uint32_t num_leaf_prims = 0;   // records in d.leaf_prims (= primitives of the scene)
   // scratch owned by the scene: stats, work counter, host-render framebuffer
   DeviceStats* d_stats = nullptr;
   unsigned int* d_counter = nullptr;
@@ -275,12 +276,19 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
     // the pool takes what is left of this workgroup's share of the CU's 160 KiB
     const uint32_t share = (160u * 1024u) / uint32_t(s->waves_per_simd) - 1024u;
     const uint32_t per_slot = POOL_LDS_WORDS * 4u * 4u;   // LDS bytes per slot, all four waves
-    uint32_t slots = share > c.lds_bytes ? (share - c.lds_bytes) / per_slot : 0;
+    // small scenes: all leaf records in LDS too (they cost a few slots, the walk gains more)
+    uint32_t leaf_bytes = 0;
+    a.lds_leaf = 0;
+    if (s->num_leaf_prims * 48u <= 4096u && !getenv("VIMG_HIP_NO_LDS_LEAF")) {
+      a.lds_leaf = s->num_leaf_prims;
+      leaf_bytes = a.lds_leaf * 48u;
+    }
+    uint32_t slots = share > c.lds_bytes + leaf_bytes ? (share - c.lds_bytes - leaf_bytes) / per_slot : 0;
     slots = std::min(slots, 256u);
     if (const char* e = getenv("VIMG_HIP_POOL_SLOTS")) slots = std::min(slots, uint32_t(atoi(e)));
     if (const char* e = getenv("VIMG_HIP_POOL_REFILL")) a.pool_refill = uint32_t(std::max(1, atoi(e)));
     a.pool_slots = std::max(slots, 8u);
-    c.lds_bytes += a.pool_slots * per_slot;
+    c.lds_bytes += a.pool_slots * per_slot + leaf_bytes;
   }
   // persistent grid: as many 4-wave workgroups as the kernel's registers and LDS let a CU hold
   // (asked of the runtime), never more than the work
@@ -358,7 +366,9 @@ int fetch_stats(VimgDeviceScene* s, const VimgRenderParams* p, VimgRenderStats* 
     static const char* names[PF_COUNT] = {"total", "v_load+logic+hit_info", "v_light_sample", "v_bsdf_sample",
                                           "v_bsdf_eval_x2", "v_finish+regen", "v_store", "w_refill+setup",
                                           "w_box_loop", "w_leaf_loop", "w_retire", "v_batches", "v_lanes",
-                                          "v_at_vertex", "w_rounds"};
+                                          "v_at_vertex", "w_rounds", "cyc_finisher", "cyc_lambertian",
+                                          "cyc_principled", "cyc_other", "lanes_finisher", "lanes_lambertian",
+                                          "lanes_principled", "lanes_other"};
     for (int k = 0; k < PF_COUNT; ++k)
       std::fprintf(stderr, "[vimg prof] %-24s %14llu  %6.2f %%\n", names[k], ds.prof[k],
                    100.0 * double(ds.prof[k]) / double(ds.prof[PF_TOTAL]));
@@ -571,6 +581,7 @@ int vimg_hip_scene_upload(const VimgScene* sc, VimgDeviceScene** out) {
   } while (0)
   UP(nodes, nodes.data(), nodes.size());
   UP(leaf_prims, leaf.data(), leaf.size());
+  s->num_leaf_prims = static_cast<uint32_t>(leaf.size());
   UP(prims, sc->prims, sc->num_prims);
   UP(tri_shade, shade.data(), shade.size());
   UP(tri_area_pdf, area_pdf.data(), area_pdf.size());
