@@ -141,6 +141,7 @@ def main():
         res = (8 * round(1800 * math.sqrt(n) / 8), 8 * round(800 * math.sqrt(n) / 8))
     scene = load_scene(res)
     dev = hip.DeviceScene(scene)
+    kernel_name = dev.kernel
     params = scene.default_params(samples=args.spp, tile_rank=rank, tile_world=n)
     W, H = res
     # a dedicated (non-default) stream: the kernels are launched on it and the HIP events that
@@ -243,7 +244,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": measured_traffic(f"disney_spheres.json, mis integrator, {args.spp} spp, {W}x{H}")
                 if n == 1 else None,
-                "kernel": "render_kernel<false>",
+                "kernel": kernel_name,
                 "bytes_per_launch": int(local_bytes),
                 "note": "algorithmic bytes on the reference layout (SURVEY.md 8d); the 2 KB scene "
                         "is LDS/L1 resident, so the kernel is VALU/latency bound, not HBM bound",

@@ -99,6 +99,10 @@ int vimg_hip_post_rgb8(const void* d_rgb, int w, int h, int tonemapper, void* d_
 /* Bytes of HBM the uploaded scene occupies. */
 int64_t vimg_hip_scene_bytes(const VimgDeviceScene* scene);
 
+/* Name of the render kernel this scene is launched with (the upload picks the build: textured or
+ * not, register budget, lane-bound or pooled scheduler) - what a rocprofv3 kernel trace will show. */
+const char* vimg_hip_scene_kernel(const VimgDeviceScene* scene);
+
 const char* vimg_hip_last_error(void);
 
 #ifdef __cplusplus

@@ -174,6 +174,7 @@ HIP_SYMBOLS = {
     "vimg_hip_post_rgb8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                     C.c_void_p]),
     "vimg_hip_scene_bytes": (i64, [C.c_void_p]),
+    "vimg_hip_scene_kernel": (C.c_char_p, [C.c_void_p]),
     "vimg_hip_last_error": (C.c_char_p, []),
 }
 

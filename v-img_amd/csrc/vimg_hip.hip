@@ -637,6 +637,15 @@ int vimg_hip_scene_free(VimgDeviceScene* s) {
   return VIMG_OK;
 }
 
+const char* vimg_hip_scene_kernel(const VimgDeviceScene* s) {
+  if (!s) return "";
+  static const char* names[2][2][2] = {
+      {{"render_kernel<false,2>", "render_kernel<false,3>"}, {"render_kernel<true,2>", "render_kernel<true,3>"}},
+      {{"render_pool_kernel<false,2>", "render_pool_kernel<false,3>"},
+       {"render_pool_kernel<true,2>", "render_pool_kernel<true,3>"}}};
+  return names[s->pooled ? 1 : 0][s->textured ? 1 : 0][s->waves_per_simd >= 3 ? 1 : 0];
+}
+
 int64_t vimg_hip_scene_bytes(const VimgDeviceScene* s) {
   return s ? static_cast<int64_t>(s->total_bytes) : 0;
 }

@@ -48,6 +48,10 @@ class DeviceScene:
     def bytes(self):
         return int(self._lib.vimg_hip_scene_bytes(self._h))
 
+    @property
+    def kernel(self):
+        return self._lib.vimg_hip_scene_kernel(self._h).decode()
+
     def shard_pixels(self, params):
         return _check(self._lib.vimg_hip_shard_pixels(self._h, C.byref(params)))
 
