@@ -99,6 +99,29 @@ int vimg_hip_post_rgb8(const void* d_rgb, int w, int h, int tonemapper, void* d_
 /* Bytes of HBM the uploaded scene occupies. */
 int64_t vimg_hip_scene_bytes(const VimgDeviceScene* scene);
 
+/* ---- the pre-step of the path on the GPU --------------------------------
+ * Host buffers in and out: these replace the OpenMP loops of the reference's scene set-up
+ * (src/image_texture.cpp:60-130,257-275; include/rng/sampling.h:113-135,168-197) while a scene
+ * is assembled; their results are byte-identical to libvimg_host's.  vimg_hip_build_mip_chain and
+ * vimg_hip_build_env_cdfs have the signatures vimg_host_set_precompute() takes. */
+
+/* Texels of all levels of the reference's chain for a w x h image (level 0 included) and the
+ * level count min(ceil(log2(min(w, h))), 15). */
+uint64_t vimg_hip_mip_chain_texels(uint32_t w, uint32_t h, uint32_t* num_levels);
+/* out_levels: 3 floats per texel, level 0 first, each level (max(w >> l, 1) x max(h >> l, 1))
+ * behind the one before; wrap modes VIMG_WRAP_*. */
+int vimg_hip_build_mip_chain(uint32_t w, uint32_t h, const float* level0_rgb, uint32_t wrap_u,
+                             uint32_t wrap_v, float* out_levels);
+/* Env-map importance tables from the w x h lat-long image: row_cdf[h + 1] (marginal over rows)
+ * and col_cdfs[h][w + 1] (one conditional per row), as ArraySampling2D builds them. */
+int vimg_hip_build_env_cdfs(const float* img_rgb, uint32_t w, uint32_t h, float* row_cdf,
+                            float* col_cdfs);
+/* out[i] = lut256[in[i]]: convert_sRGB_to_linear on 8-bit data with the caller's table
+ * (vimg_host_srgb8_lut evaluates the reference's expression for the 256 inputs). */
+int vimg_hip_lut8_to_float(const uint8_t* in, uint64_t n, const float* lut256, float* out);
+/* convert_RGB_to_normal: normalize((rgb / 127.5 - 1) * (scale, scale, 1)) per pixel. */
+int vimg_hip_rgb8_to_normal(const uint8_t* rgb8, uint64_t n_pixels, float scale, float* out_xyz);
+
 /* Name of the render kernel this scene is launched with (the upload picks the build: textured or
  * not, register budget, lane-bound or pooled scheduler) - what a rocprofv3 kernel trace will show. */
 const char* vimg_hip_scene_kernel(const VimgDeviceScene* scene);

@@ -65,6 +65,22 @@ void vimg_host_set_background_const(VimgHostScene* s, const float rgb[3], int ad
 int vimg_host_set_background_envmap(VimgHostScene* s, int env_tex, const float world_to_env[16],
                                     const float env_to_world[16], float radiance_scale);
 
+/* ---- precompute of image textures and env-map tables ----
+ * add_texture_image builds the mip chain and set_background_envmap the sampling CDFs with the
+ * host loops (OpenMP, as the reference).  A caller that has libvimg_hip loaded installs its GPU
+ * builders here (vimg_hip_build_mip_chain / vimg_hip_build_env_cdfs have these signatures; both
+ * return 0 on success - on failure the host loops run).  NULL restores the host loops. */
+typedef int (*vimg_mip_builder_fn)(uint32_t w, uint32_t h, const float* level0_rgb,
+                                   uint32_t wrap_u, uint32_t wrap_v, float* out_levels);
+typedef int (*vimg_env_cdf_builder_fn)(const float* img_rgb, uint32_t w, uint32_t h,
+                                       float* row_cdf, float* col_cdfs);
+void vimg_host_set_precompute(vimg_mip_builder_fn mip, vimg_env_cdf_builder_fn cdf);
+/* 8-bit image conversions of the reference's texture loaders (src/image_texture.cpp:257-275):
+ * sRGB -> linear (table of the 256 inputs, and applied), RGB -> unit normal. */
+void vimg_host_srgb8_lut(float lut[256]);
+void vimg_host_srgb8_to_linear(const uint8_t* in, uint64_t n, float* out);
+void vimg_host_rgb8_to_normal(const uint8_t* rgb8, uint64_t n_pixels, float scale, float* out_xyz);
+
 /* ---- finalisation ---- */
 /* Primitive AABBs/centres as setup_for_bvh, then the chosen builder (sweep: max 8 prims per
  * leaf as src/main.cpp:200; binned: 16 bins as src/main.cpp:41). */

@@ -202,6 +202,54 @@ def test_mip_chain_and_env_cdfs():
     assert v.lights[v.num_lights - 1].type == abi.LIGHT_BACKGROUND
 
 
+def test_precompute_hooks_and_8bit_conversions():
+    """vimg_host_set_precompute: an installed builder replaces the host loops (and its failure is
+    an error, not a silent second path); the 8-bit conversions follow the reference's formulas."""
+    rng = np.random.default_rng(5)
+    img = rng.random((8, 16, 3), dtype=np.float32)
+    calls = []
+    MIP = C.CFUNCTYPE(C.c_int, C.c_uint32, C.c_uint32, abi.Pf32, C.c_uint32, C.c_uint32, abi.Pf32)
+    CDF = C.CFUNCTYPE(C.c_int, abi.Pf32, C.c_uint32, C.c_uint32, abi.Pf32, abi.Pf32)
+
+    def mip(w, h, level0, wu, wv, out):
+        calls.append(("mip", w, h, wu, wv))
+        n = w * h + (w // 2) * (h // 2) + (w // 4) * (h // 4)     # ceil(log2 8) = 3 levels
+        np.ctypeslib.as_array(out, (n * 3,))[:] = 7.0
+        return 0
+
+    def cdf_fail(img_p, w, h, row, col):
+        calls.append(("cdf", w, h))
+        return -1
+
+    mip_c, cdf_c = MIP(mip), CDF(cdf_fail)
+    lib = abi.host_lib()
+    lib.vimg_host_set_precompute(C.cast(mip_c, C.c_void_p), C.cast(cdf_c, C.c_void_p))
+    try:
+        s = host.HostScene()
+        t = s.add_texture_image(img, abi.WRAP_CLAMP, abi.WRAP_MIRROR)
+        assert calls == [("mip", 16, 8, abi.WRAP_CLAMP, abi.WRAP_MIRROR)]
+        with pytest.raises(host.HostError, match="CDF builder failed"):
+            s.set_background_envmap(t)
+        assert calls[-1] == ("cdf", 16, 8)
+    finally:
+        lib.vimg_host_set_precompute(None, None)
+    s2 = host.HostScene()
+    s2.add_texture_image(img, abi.WRAP_CLAMP, abi.WRAP_MIRROR)     # host loops again
+    assert len(calls) == 2
+
+    lut = host.srgb8_lut()
+    x = np.arange(256, dtype=np.float64) / 255.0
+    want = np.where(x <= 0.04045, x / 12.92, ((x + 0.055) / 1.055) ** 2.4)
+    assert lut[0] == 0 and lut[255] == 1 and np.allclose(lut, want, rtol=1e-6, atol=1e-9)
+    vals = rng.integers(0, 256, size=(5, 7, 3), dtype=np.uint8)
+    assert np.array_equal(host.srgb8_to_linear(vals), lut[vals])
+    nm = host.rgb8_to_normal(vals, scale=0.5)
+    v = vals.astype(np.float64) / 127.5 - 1.0
+    v[..., :2] *= 0.5
+    v /= np.linalg.norm(v, axis=-1, keepdims=True)
+    assert np.allclose(nm, v, atol=2e-7)
+
+
 # ------------------------------------------------------------------------------- post chain
 def test_tonemap_srgb_quantise_and_png(tmp_path):
     img = np.zeros((2, 4, 3), np.float32)

@@ -148,6 +148,10 @@ HOST_SYMBOLS = {
     "vimg_host_add_sphere": (C.c_int, [C.c_void_p, Pf32, f32, u32]),
     "vimg_host_set_background_const": (None, [C.c_void_p, Pf32, C.c_int]),
     "vimg_host_set_background_envmap": (C.c_int, [C.c_void_p, C.c_int, Pf32, Pf32, f32]),
+    "vimg_host_set_precompute": (None, [C.c_void_p, C.c_void_p]),
+    "vimg_host_srgb8_lut": (None, [Pf32]),
+    "vimg_host_srgb8_to_linear": (None, [C.POINTER(C.c_uint8), C.c_uint64, Pf32]),
+    "vimg_host_rgb8_to_normal": (None, [C.POINTER(C.c_uint8), C.c_uint64, f32, Pf32]),
     "vimg_host_build_bvh": (C.c_int, [C.c_void_p, C.c_int]),
     "vimg_host_scene_view": (PScene, [C.c_void_p]),
     "vimg_host_default_params": (None, [C.c_void_p, PParams]),
@@ -173,6 +177,11 @@ HIP_SYMBOLS = {
     "vimg_hip_time_renders": (C.c_int, [C.c_void_p, PParams, C.c_void_p, C.c_int, Pf32]),
     "vimg_hip_post_rgb8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                     C.c_void_p]),
+    "vimg_hip_mip_chain_texels": (C.c_uint64, [u32, u32, C.POINTER(u32)]),
+    "vimg_hip_build_mip_chain": (C.c_int, [u32, u32, Pf32, u32, u32, Pf32]),
+    "vimg_hip_build_env_cdfs": (C.c_int, [Pf32, u32, u32, Pf32, Pf32]),
+    "vimg_hip_lut8_to_float": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint64, Pf32, Pf32]),
+    "vimg_hip_rgb8_to_normal": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint64, f32, Pf32]),
     "vimg_hip_scene_bytes": (i64, [C.c_void_p]),
     "vimg_hip_scene_kernel": (C.c_char_p, [C.c_void_p]),
     "vimg_hip_last_error": (C.c_char_p, []),

@@ -1,0 +1,179 @@
+// The step immediately BEFORE the path on the GPU: what the reference does
+// once per scene in OpenMP loops on the host, and what every render then only reads.
+//   mip chain      ImageTexture ctor            reference src/image_texture.cpp:60-130
+//   bilinear tap   col_at_uv_mipmap             reference src/image_texture.cpp:132-160
+//   wrapping       handle_wrapping              reference include/texture/texture_common.h:22-53
+//   sRGB -> linear convert_sRGB_to_linear       reference src/image_texture.cpp:257-263
+//   normal map     convert_RGB_to_normal        reference src/image_texture.cpp:265-275
+//   env-map CDFs   ArraySampling1D/2D ctors     reference include/rng/sampling.h:113-135,168-197
+// All of it is elementwise or short-stencil float work bounded by HBM traffic; every kernel
+// evaluates the host library's float expression tree (v-img_amd/host/texture_build.cpp, same
+// -ffp-contract=off), so the tables are byte-identical to the host-built ones
+// (tests/test_gpu_parity.py::test_precompute_*).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_math.h"
+#include "device_scene.h"
+
+namespace vimg {
+
+// ------------------------------------------------------------------------------------ mip chain
+VD float pre_wrap_coord(float coord, uint32_t mode) {
+  if (mode == VIMG_WRAP_REPEAT) {
+    const float fraction = coord - static_cast<float>(static_cast<int>(coord));
+    return __builtin_signbit(fraction) ? 1.f + fraction : fraction;
+  }
+  if (mode == VIMG_WRAP_MIRROR) {
+    const int int_part = static_cast<int>(coord);
+    const float fraction = coord - static_cast<float>(int_part);
+    if (__builtin_signbit(fraction)) return (int_part % 2) ? __builtin_fabsf(fraction) : 1.f + fraction;
+    return fraction;
+  }
+  return clampf(coord, 0.f, 1.f);   // ClampToEdge and anything unknown
+}
+
+VD f3 pre_tap(const float* __restrict__ level, uint32_t mip_w, uint32_t mip_h, uint32_t wrap_u,
+              uint32_t wrap_v, float u, float v) {
+  const float pixel_u = pre_wrap_coord(u, wrap_u) * static_cast<float>(mip_w);
+  const float pixel_v = pre_wrap_coord(v, wrap_v) * static_cast<float>(mip_h);
+  const int cx = clampi(static_cast<int>(pixel_u), 0, static_cast<int>(mip_w) - 1);
+  const int cy = clampi(static_cast<int>(pixel_v), 0, static_cast<int>(mip_h) - 1);
+  const int nx = clampi(cx + 1, 0, static_cast<int>(mip_w) - 1);
+  const int ny = clampi(cy + 1, 0, static_cast<int>(mip_h) - 1);
+  const float fx = pixel_u - static_cast<float>(cx), fy = pixel_v - static_cast<float>(cy);
+  auto at = [&](int x, int y) {
+    const float* p = level + (static_cast<size_t>(x) + static_cast<size_t>(y) * mip_w) * 3;
+    return f3{p[0], p[1], p[2]};
+  };
+  const f3 a = mix3(at(cx, cy), at(nx, cy), fx);
+  const f3 b = mix3(at(cx, ny), at(nx, ny), fx);
+  return mix3(a, b, fy);
+}
+
+// One thread per texel of the new level: the 8-tap downsampling filter (4 diagonal positive taps,
+// 4 axial negative ones), each tap a bilinear fetch of the previous level.  The stencil spans 7x7
+// texels of the previous level; neighbouring threads share them through L1/L2, so HBM sees the
+// previous level once and the new level once.
+__global__ void __launch_bounds__(256)
+pre_mip_level_kernel(const float* __restrict__ prev, uint32_t prev_w, uint32_t prev_h,
+                     float* __restrict__ next, uint32_t next_w, uint32_t next_h, uint32_t wrap_u,
+                     uint32_t wrap_v) {
+  const uint32_t x = blockIdx.x * 32u + (threadIdx.x & 31u);
+  const uint32_t y = blockIdx.y * 8u + (threadIdx.x >> 5);
+  if (x >= next_w || y >= next_h) return;
+  const float inv_x = 1.f / static_cast<float>(prev_w), inv_y = 1.f / static_cast<float>(prev_h);
+  const float cu = static_cast<float>(2u * x) * inv_x, cv = static_cast<float>(2u * y) * inv_y;
+  const float kOff[8][2] = {{-0.75777f, -0.75777f}, {0.75777f, -0.75777f}, {0.75777f, 0.75777f},
+                            {-0.75777f, 0.75777f},  {-2.907f, 0.f},        {2.907f, 0.f},
+                            {0.f, -2.907f},         {0.f, 2.907f}};
+  f3 sum{0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float wgt = k < 4 ? 0.37487566f : -0.12487566f;
+    const f3 c = pre_tap(prev, prev_w, prev_h, wrap_u, wrap_v, cu + kOff[k][0] * inv_x,
+                         cv + kOff[k][1] * inv_y);
+    sum.x += wgt * c.x;
+    sum.y += wgt * c.y;
+    sum.z += wgt * c.z;
+  }
+  if (sum.x < 0) sum.x = 0.f;
+  if (sum.y < 0) sum.y = 0.f;
+  if (sum.z < 0) sum.z = 0.f;
+  float* o = next + (static_cast<size_t>(x) + static_cast<size_t>(y) * next_w) * 3;
+  o[0] = sum.x;
+  o[1] = sum.y;
+  o[2] = sum.z;
+}
+
+// ------------------------------------------------------------------- 8-bit image conversions
+// convert_sRGB_to_linear on 8-bit data is a function of 256 inputs: the table is evaluated once by
+// the caller with the reference's expression (x/255, then /12.92 or powf) and the kernel gathers.
+__global__ void __launch_bounds__(256)
+pre_lut8_kernel(const uint8_t* __restrict__ in, size_t n, const float* __restrict__ lut,
+                float* __restrict__ out) {
+  __shared__ float s_lut[256];
+  s_lut[threadIdx.x] = lut[threadIdx.x];
+  __syncthreads();
+  for (size_t i = size_t(blockIdx.x) * 256u + threadIdx.x; i < n; i += size_t(gridDim.x) * 256u)
+    out[i] = s_lut[in[i]];
+}
+
+// convert_RGB_to_normal: n = rgb/127.5 - 1, xy scaled, normalised
+__global__ void __launch_bounds__(256)
+pre_normal8_kernel(const uint8_t* __restrict__ in, size_t n_pixels, float scale,
+                   float* __restrict__ out) {
+  for (size_t i = size_t(blockIdx.x) * 256u + threadIdx.x; i < n_pixels; i += size_t(gridDim.x) * 256u) {
+    f3 v{static_cast<float>(in[i * 3 + 0]), static_cast<float>(in[i * 3 + 1]),
+         static_cast<float>(in[i * 3 + 2])};
+    v = (v / 127.5f) - f3{1.f, 1.f, 1.f};
+    v.x *= scale;
+    v.y *= scale;
+    v = normalize(v);
+    out[i * 3 + 0] = v.x, out[i * 3 + 1] = v.y, out[i * 3 + 2] = v.z;
+  }
+}
+
+// ---------------------------------------------------------------------------------- env-map CDFs
+// f(x, y) = luminance(texel) * sin(pi * (y + 0.5) / H); the H sines are a table evaluated by the
+// caller in double as the reference does (std::sin(std::numbers::pi * v)).
+__global__ void __launch_bounds__(256)
+pre_env_lum_kernel(const float* __restrict__ img, uint32_t w, uint32_t h,
+                   const float* __restrict__ sin_elevation, float* __restrict__ lum) {
+  const size_t n = size_t(w) * h;
+  for (size_t i = size_t(blockIdx.x) * 256u + threadIdx.x; i < n; i += size_t(gridDim.x) * 256u) {
+    const float* p = img + i * 3;
+    const float l = p[0] * 0.212671f + p[1] * 0.715160f + p[2] * 0.072169f;   // luminance()
+    lum[i] = l * sin_elevation[i / w];
+  }
+}
+
+// ArraySampling1D ctor, unnormalised part: cdf[r][0] = 0, cdf[r][x] = cdf[r][x-1] + |f[r][x-1]|.
+// The float additions of a row are sequential by definition (a parallel scan would round
+// differently), so one lane owns one row; a wave owns 64 rows and moves 64x64 tiles through LDS so
+// that both the loads of f and the stores of the cdf are coalesced rows of 256 bytes.  The row
+// pitch of the tile is 65 dwords: lane l walking row l touches bank (65 l + j) mod 64 = (l + j).
+__global__ void __launch_bounds__(64)
+pre_cdf_scan_kernel(const float* __restrict__ f, uint32_t rows, uint32_t n, float* __restrict__ cdf,
+                    float* __restrict__ row_integral) {
+  __shared__ float tile[64 * 65];
+  const uint32_t lane = threadIdx.x, row0 = blockIdx.x * 64u;
+  const uint32_t my_row = row0 + lane;
+  float acc = 0.f;
+  if (my_row < rows) cdf[size_t(my_row) * (n + 1)] = 0.f;
+  for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
+    const uint32_t cols = (n - c0 < 64u) ? n - c0 : 64u;
+    for (uint32_t r = 0; r < 64u; ++r)
+      if (row0 + r < rows && lane < cols) tile[r * 65u + lane] = f[size_t(row0 + r) * n + c0 + lane];
+    __syncthreads();
+    if (my_row < rows)
+      for (uint32_t j = 0; j < cols; ++j) {
+        acc = acc + __builtin_fabsf(tile[lane * 65u + j]);
+        tile[lane * 65u + j] = acc;
+      }
+    __syncthreads();
+    for (uint32_t r = 0; r < 64u; ++r)
+      if (row0 + r < rows && lane < cols)
+        cdf[size_t(row0 + r) * (n + 1) + c0 + lane + 1u] = tile[r * 65u + lane];
+    __syncthreads();
+  }
+  if (my_row < rows) row_integral[my_row] = acc;
+}
+
+// ArraySampling1D ctor, normalisation: /= func_int, or the uniform ramp i/n when func_int == 0
+__global__ void __launch_bounds__(256)
+pre_cdf_normalise_kernel(float* __restrict__ cdf, uint32_t rows, uint32_t n,
+                         const float* __restrict__ row_integral) {
+  const size_t total = size_t(rows) * (n + 1);
+  for (size_t i = size_t(blockIdx.x) * 256u + threadIdx.x; i < total; i += size_t(gridDim.x) * 256u) {
+    const uint32_t r = static_cast<uint32_t>(i / (n + 1)), k = static_cast<uint32_t>(i % (n + 1));
+    const float func_int = row_integral[r];
+    if (func_int == 0)
+      cdf[i] = static_cast<float>(k) / static_cast<float>(n);
+    else
+      cdf[i] = cdf[i] / func_int;
+  }
+}
+
+}  // namespace vimg

@@ -15,6 +15,7 @@
 
 #include "../../include/vimg_hip.h"
 #include "post_kernels.h"
+#include "pre_kernels.h"
 #include "render_kernels.h"
 #include "render_pool_kernel.h"
 
@@ -778,6 +779,140 @@ int vimg_hip_post_rgb8(const void* d_rgb, int w, int h, int tonemapper, void* d_
                      static_cast<unsigned char*>(d_rgb8));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(st));
+  return VIMG_OK;
+}
+
+// ---- the pre-step of the path on the GPU; host buffers in and out: these
+// replace the host library's OpenMP loops while a scene is being assembled, before the upload
+namespace {
+struct PreBuf {   // device scratch freed on every exit path
+  void* p = nullptr;
+  ~PreBuf() { if (p) (void)hipFree(p); }
+  float* f32() { return static_cast<float*>(p); }
+  uint8_t* u8() { return static_cast<uint8_t*>(p); }
+};
+int pre_ready() {
+  if (g_device < 0) return vimg_hip_init(0);
+  return VIMG_OK;
+}
+uint32_t pre_grid(size_t n) { return static_cast<uint32_t>(std::min<size_t>((n + 255) / 256, 65536)); }
+}  // namespace
+
+uint64_t vimg_hip_mip_chain_texels(uint32_t w, uint32_t h, uint32_t* num_levels) {
+  if (w == 0 || h == 0) {
+    if (num_levels) *num_levels = 0;
+    return 0;
+  }
+  // level count of the reference: min(ceil(log2(min(w, h))), 15), never fewer than level 0
+  const int levels = std::max(1, std::min(static_cast<int>(std::ceil(std::log2(static_cast<float>(std::min(w, h))))),
+                                          VIMG_MAX_MIP_LEVELS));
+  uint64_t total = 0;
+  uint32_t lw = w, lh = h;
+  for (int l = 0; l < levels; ++l) {
+    total += uint64_t(lw) * lh;
+    lw = std::max(lw / 2u, 1u), lh = std::max(lh / 2u, 1u);
+  }
+  if (num_levels) *num_levels = static_cast<uint32_t>(levels);
+  return total;
+}
+
+int vimg_hip_build_mip_chain(uint32_t w, uint32_t h, const float* level0, uint32_t wrap_u,
+                             uint32_t wrap_v, float* out_levels) {
+  if (!level0 || !out_levels || w == 0 || h == 0 || wrap_u > 2 || wrap_v > 2)
+    return fail(VIMG_E_INVALID, "build_mip_chain: bad arguments");
+  if (int rc = pre_ready()) return rc;
+  uint32_t levels = 0;
+  const uint64_t texels = vimg_hip_mip_chain_texels(w, h, &levels);
+  PreBuf d;
+  HIP_TRY(hipMalloc(&d.p, texels * 3 * sizeof(float)));
+  float* base = d.f32();
+  HIP_TRY(hipMemcpyAsync(base, level0, size_t(w) * h * 3 * sizeof(float), hipMemcpyHostToDevice, g_stream));
+  uint64_t prev_off = 0;
+  uint32_t pw = w, ph = h;
+  for (uint32_t l = 1; l < levels; ++l) {
+    const uint32_t nw = std::max(pw / 2u, 1u), nh = std::max(ph / 2u, 1u);
+    const uint64_t next_off = prev_off + uint64_t(pw) * ph;
+    hipLaunchKernelGGL(pre_mip_level_kernel, dim3((nw + 31) / 32, (nh + 7) / 8), dim3(256), 0, g_stream,
+                       base + prev_off * 3, pw, ph, base + next_off * 3, nw, nh, wrap_u, wrap_v);
+    prev_off = next_off;
+    pw = nw, ph = nh;
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out_levels, base, texels * 3 * sizeof(float), hipMemcpyDeviceToHost, g_stream));
+  HIP_TRY(hipStreamSynchronize(g_stream));
+  return VIMG_OK;
+}
+
+int vimg_hip_build_env_cdfs(const float* img, uint32_t w, uint32_t h, float* row_cdf, float* col_cdfs) {
+  if (!img || !row_cdf || !col_cdfs || w == 0 || h == 0)
+    return fail(VIMG_E_INVALID, "build_env_cdfs: bad arguments");
+  if (int rc = pre_ready()) return rc;
+  // sin(pi * v) per row, in double as the reference evaluates it (sampling.h:180-181)
+  std::vector<float> sin_elev(h);
+  for (uint32_t y = 0; y < h; ++y) {
+    float v = (static_cast<float>(y) + 0.5f) / static_cast<float>(h);
+    sin_elev[y] = static_cast<float>(std::sin(3.141592653589793238462643383279502884 * v));
+  }
+  const size_t n = size_t(w) * h;
+  PreBuf d_img, d_sin, d_lum, d_cdf, d_rowint, d_rowcdf, d_rowtot;
+  HIP_TRY(hipMalloc(&d_img.p, n * 3 * sizeof(float)));
+  HIP_TRY(hipMalloc(&d_sin.p, h * sizeof(float)));
+  HIP_TRY(hipMalloc(&d_lum.p, n * sizeof(float)));
+  HIP_TRY(hipMalloc(&d_cdf.p, size_t(h) * (w + 1) * sizeof(float)));
+  HIP_TRY(hipMalloc(&d_rowint.p, h * sizeof(float)));
+  HIP_TRY(hipMalloc(&d_rowcdf.p, (size_t(h) + 1) * sizeof(float)));
+  HIP_TRY(hipMalloc(&d_rowtot.p, sizeof(float)));
+  HIP_TRY(hipMemcpyAsync(d_img.p, img, n * 3 * sizeof(float), hipMemcpyHostToDevice, g_stream));
+  HIP_TRY(hipMemcpyAsync(d_sin.p, sin_elev.data(), h * sizeof(float), hipMemcpyHostToDevice, g_stream));
+  hipLaunchKernelGGL(pre_env_lum_kernel, dim3(pre_grid(n)), dim3(256), 0, g_stream, d_img.f32(), w, h,
+                     d_sin.f32(), d_lum.f32());
+  // one conditional distribution per image row, then the marginal over the row integrals
+  hipLaunchKernelGGL(pre_cdf_scan_kernel, dim3((h + 63) / 64), dim3(64), 0, g_stream, d_lum.f32(), h, w,
+                     d_cdf.f32(), d_rowint.f32());
+  hipLaunchKernelGGL(pre_cdf_normalise_kernel, dim3(pre_grid(size_t(h) * (w + 1))), dim3(256), 0, g_stream,
+                     d_cdf.f32(), h, w, d_rowint.f32());
+  hipLaunchKernelGGL(pre_cdf_scan_kernel, dim3(1), dim3(64), 0, g_stream, d_rowint.f32(), 1u, h,
+                     d_rowcdf.f32(), d_rowtot.f32());
+  hipLaunchKernelGGL(pre_cdf_normalise_kernel, dim3(pre_grid(size_t(h) + 1)), dim3(256), 0, g_stream,
+                     d_rowcdf.f32(), 1u, h, d_rowtot.f32());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(col_cdfs, d_cdf.p, size_t(h) * (w + 1) * sizeof(float), hipMemcpyDeviceToHost, g_stream));
+  HIP_TRY(hipMemcpyAsync(row_cdf, d_rowcdf.p, (size_t(h) + 1) * sizeof(float), hipMemcpyDeviceToHost, g_stream));
+  HIP_TRY(hipStreamSynchronize(g_stream));
+  return VIMG_OK;
+}
+
+int vimg_hip_lut8_to_float(const uint8_t* in, uint64_t n, const float* lut256, float* out) {
+  if (!in || !lut256 || !out) return fail(VIMG_E_INVALID, "lut8_to_float: bad arguments");
+  if (n == 0) return VIMG_OK;
+  if (int rc = pre_ready()) return rc;
+  PreBuf d_in, d_lut, d_out;
+  HIP_TRY(hipMalloc(&d_in.p, n));
+  HIP_TRY(hipMalloc(&d_lut.p, 256 * sizeof(float)));
+  HIP_TRY(hipMalloc(&d_out.p, n * sizeof(float)));
+  HIP_TRY(hipMemcpyAsync(d_in.p, in, n, hipMemcpyHostToDevice, g_stream));
+  HIP_TRY(hipMemcpyAsync(d_lut.p, lut256, 256 * sizeof(float), hipMemcpyHostToDevice, g_stream));
+  hipLaunchKernelGGL(pre_lut8_kernel, dim3(pre_grid(n)), dim3(256), 0, g_stream, d_in.u8(), size_t(n),
+                     d_lut.f32(), d_out.f32());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, d_out.p, n * sizeof(float), hipMemcpyDeviceToHost, g_stream));
+  HIP_TRY(hipStreamSynchronize(g_stream));
+  return VIMG_OK;
+}
+
+int vimg_hip_rgb8_to_normal(const uint8_t* rgb8, uint64_t n_pixels, float scale, float* out) {
+  if (!rgb8 || !out) return fail(VIMG_E_INVALID, "rgb8_to_normal: bad arguments");
+  if (n_pixels == 0) return VIMG_OK;
+  if (int rc = pre_ready()) return rc;
+  PreBuf d_in, d_out;
+  HIP_TRY(hipMalloc(&d_in.p, n_pixels * 3));
+  HIP_TRY(hipMalloc(&d_out.p, n_pixels * 3 * sizeof(float)));
+  HIP_TRY(hipMemcpyAsync(d_in.p, rgb8, n_pixels * 3, hipMemcpyHostToDevice, g_stream));
+  hipLaunchKernelGGL(pre_normal8_kernel, dim3(pre_grid(n_pixels)), dim3(256), 0, g_stream, d_in.u8(),
+                     size_t(n_pixels), scale, d_out.f32());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, d_out.p, n_pixels * 3 * sizeof(float), hipMemcpyDeviceToHost, g_stream));
+  HIP_TRY(hipStreamSynchronize(g_stream));
   return VIMG_OK;
 }
 

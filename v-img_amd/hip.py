@@ -151,3 +151,68 @@ def post_rgb8(image, tonemapper=1, stream=None):
 
 
 __all__ = ["DeviceScene", "post_rgb8", "HipError", "device_count", "init", "make_params"]
+
+
+# ---- the pre-step of the path on the GPU (include/vimg_hip.h) ----------
+def build_mip_chain(level0, wrap_u=abi.WRAP_REPEAT, wrap_v=abi.WRAP_REPEAT):
+    """All mip levels of an [H, W, 3] float image, level 0 first: (flat [texels, 3] array,
+    list of per-level (offset_in_texels, w, h))."""
+    lib = abi.hip_lib()
+    img = np.ascontiguousarray(level0, dtype=np.float32)
+    h, w = img.shape[:2]
+    n_levels = abi.u32(0)
+    texels = int(lib.vimg_hip_mip_chain_texels(w, h, C.byref(n_levels)))
+    out = np.empty((texels, 3), dtype=np.float32)
+    _check(lib.vimg_hip_build_mip_chain(w, h, img.ctypes.data_as(abi.Pf32), wrap_u, wrap_v,
+                                        out.ctypes.data_as(abi.Pf32)))
+    levels, off, lw, lh = [], 0, w, h
+    for _ in range(n_levels.value):
+        levels.append((off, lw, lh))
+        off += lw * lh
+        lw, lh = max(lw // 2, 1), max(lh // 2, 1)
+    return out, levels
+
+
+def build_env_cdfs(img):
+    """(row_cdf [H+1], col_cdfs [H, W+1]) of a lat-long [H, W, 3] float image."""
+    lib = abi.hip_lib()
+    a = np.ascontiguousarray(img, dtype=np.float32)
+    h, w = a.shape[:2]
+    row = np.empty(h + 1, dtype=np.float32)
+    col = np.empty((h, w + 1), dtype=np.float32)
+    _check(lib.vimg_hip_build_env_cdfs(a.ctypes.data_as(abi.Pf32), w, h, row.ctypes.data_as(abi.Pf32),
+                                       col.ctypes.data_as(abi.Pf32)))
+    return row, col
+
+
+def lut8_to_float(values_u8, lut256):
+    lib = abi.hip_lib()
+    a = np.ascontiguousarray(values_u8, dtype=np.uint8)
+    lut = np.ascontiguousarray(lut256, dtype=np.float32)
+    assert lut.size == 256
+    out = np.empty(a.shape, dtype=np.float32)
+    _check(lib.vimg_hip_lut8_to_float(a.ctypes.data_as(C.POINTER(C.c_uint8)), a.size,
+                                      lut.ctypes.data_as(abi.Pf32), out.ctypes.data_as(abi.Pf32)))
+    return out
+
+
+def rgb8_to_normal(rgb8, scale=1.0):
+    lib = abi.hip_lib()
+    a = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    assert a.shape[-1] == 3
+    out = np.empty(a.shape, dtype=np.float32)
+    _check(lib.vimg_hip_rgb8_to_normal(a.ctypes.data_as(C.POINTER(C.c_uint8)), a.size // 3, scale,
+                                       out.ctypes.data_as(abi.Pf32)))
+    return out
+
+
+def install_gpu_precompute(enable=True):
+    """Make libvimg_host build mip chains and env-map CDFs with the GPU kernels (or, with
+    enable=False, with its own loops again)."""
+    host = abi.host_lib()
+    if not enable:
+        host.vimg_host_set_precompute(None, None)
+        return
+    lib = abi.hip_lib()
+    host.vimg_host_set_precompute(C.cast(lib.vimg_hip_build_mip_chain, C.c_void_p),
+                                  C.cast(lib.vimg_hip_build_env_cdfs, C.c_void_p))

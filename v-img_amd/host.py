@@ -219,3 +219,25 @@ def write_png(path, rgb8):
     if lib.vimg_host_write_png(str(path).encode(), img.ctypes.data_as(C.POINTER(C.c_uint8)),
                                img.shape[1], img.shape[0]) != 0:
         raise HostError(lib.vimg_host_last_error().decode())
+
+
+def srgb8_lut():
+    lut = np.empty(256, dtype=np.float32)
+    abi.host_lib().vimg_host_srgb8_lut(lut.ctypes.data_as(abi.Pf32))
+    return lut
+
+
+def srgb8_to_linear(values_u8):
+    a = np.ascontiguousarray(values_u8, dtype=np.uint8)
+    out = np.empty(a.shape, dtype=np.float32)
+    abi.host_lib().vimg_host_srgb8_to_linear(a.ctypes.data_as(C.POINTER(C.c_uint8)), a.size,
+                                             out.ctypes.data_as(abi.Pf32))
+    return out
+
+
+def rgb8_to_normal(rgb8, scale=1.0):
+    a = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    out = np.empty(a.shape, dtype=np.float32)
+    abi.host_lib().vimg_host_rgb8_to_normal(a.ctypes.data_as(C.POINTER(C.c_uint8)), a.size // 3,
+                                            scale, out.ctypes.data_as(abi.Pf32))
+    return out

@@ -431,7 +431,7 @@ int vimg_host_add_texture_image(VimgHostScene* s, uint32_t w, uint32_t h, const 
     return -1;
   }
   VimgTexture t{};
-  build_mip_chain(w, h, rgb, wrap_u, wrap_v, t, s->texels);
+  if (!build_mip_chain(w, h, rgb, wrap_u, wrap_v, t, s->texels)) return -1;
   s->textures.push_back(t);
   return static_cast<int>(s->textures.size() - 1);
 }
@@ -523,8 +523,9 @@ int vimg_host_set_background_envmap(VimgHostScene* s, int env_tex, const float w
   std::memcpy(bg.env_to_world, env_to_world, 64);
   bg.radiance_scale = radiance_scale;
   const VimgTexture& t = s->textures[env_tex];
-  build_env_cdfs(s->texels.data() + t.level_offset[0] * 3, t.width, t.height, s->cdf_pool,
-                 bg.row_cdf_offset, bg.col_cdf_offset);
+  if (!build_env_cdfs(s->texels.data() + t.level_offset[0] * 3, t.width, t.height, s->cdf_pool,
+                      bg.row_cdf_offset, bg.col_cdf_offset))
+    return -1;
   s->background = bg;
   s->lights.push_back(VimgLight{VIMG_LIGHT_BACKGROUND, 0});
   return 0;

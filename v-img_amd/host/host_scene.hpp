@@ -50,9 +50,9 @@ HostBVH build_bin_bvh(const std::vector<PrimBounds>& bboxes, const std::vector<h
                       size_t num_bins);
 
 // texture_build.cpp
-void build_mip_chain(uint32_t w, uint32_t h, const float* level0, uint32_t wrap_u, uint32_t wrap_v,
+bool build_mip_chain(uint32_t w, uint32_t h, const float* level0, uint32_t wrap_u, uint32_t wrap_v,
                      VimgTexture& tex, std::vector<float>& texel_pool);
-void build_env_cdfs(const float* level0, uint32_t w, uint32_t h, std::vector<float>& pool,
+bool build_env_cdfs(const float* level0, uint32_t w, uint32_t h, std::vector<float>& pool,
                     uint64_t& row_off, uint64_t& col_off);
 
 void host_set_error(const std::string& msg);

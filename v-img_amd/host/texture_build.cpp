@@ -55,9 +55,19 @@ Rgb tap(const float* level, uint32_t mip_w, uint32_t mip_h, uint32_t wrap_u, uin
   return mix(a, b, fy);
 }
 
+// builders installed by vimg_host_set_precompute (e.g. libvimg_hip's GPU kernels); null = the
+// loops below
+vimg_mip_builder_fn g_mip_builder = nullptr;
+vimg_env_cdf_builder_fn g_cdf_builder = nullptr;
+
 }  // namespace
 
-void build_mip_chain(uint32_t w, uint32_t h, const float* level0, uint32_t wrap_u, uint32_t wrap_v,
+extern "C" void vimg_host_set_precompute(vimg_mip_builder_fn mip, vimg_env_cdf_builder_fn cdf) {
+  g_mip_builder = mip;
+  g_cdf_builder = cdf;
+}
+
+bool build_mip_chain(uint32_t w, uint32_t h, const float* level0, uint32_t wrap_u, uint32_t wrap_v,
                      VimgTexture& tex, std::vector<float>& pool) {
   tex.type = VIMG_TEX_IMAGE;
   tex.width = w;
@@ -67,6 +77,26 @@ void build_mip_chain(uint32_t w, uint32_t h, const float* level0, uint32_t wrap_
   const int num_levels = std::min(
       static_cast<int>(std::ceil(std::log2(static_cast<float>(std::min(w, h))))),
       VIMG_MAX_MIP_LEVELS);
+
+  if (g_mip_builder) {
+    // an installed builder fills all levels at once, level 0 first
+    uint64_t total = 0, off = pool.size() / 3;
+    uint32_t lw = w, lh = h;
+    tex.num_levels = static_cast<uint32_t>(std::max(num_levels, 1));
+    for (uint32_t l = 0; l < tex.num_levels; ++l) {
+      tex.level_offset[l] = off + total;
+      total += uint64_t(lw) * lh;
+      lw = std::max(lw / 2u, 1u), lh = std::max(lh / 2u, 1u);
+    }
+    const size_t base = pool.size();
+    pool.resize(base + total * 3);
+    if (g_mip_builder(w, h, level0, wrap_u, wrap_v, pool.data() + base) == 0) return true;
+    // an installed builder that fails is an error of the caller's set-up (no GPU ...): no silent
+    // second path
+    pool.resize(base);
+    host_set_error("the installed mip-chain builder failed");
+    return false;
+  }
 
   tex.level_offset[0] = pool.size() / 3;
   pool.insert(pool.end(), level0, level0 + static_cast<size_t>(w) * h * 3);
@@ -113,6 +143,7 @@ void build_mip_chain(uint32_t w, uint32_t h, const float* level0, uint32_t wrap_
     prev_w = next_w;
     prev_h = next_h;
   }
+  return true;
 }
 
 namespace {
@@ -129,8 +160,18 @@ float build_cdf1d(const float* f, size_t n, float* cdf) {
 }
 }  // namespace
 
-void build_env_cdfs(const float* img, uint32_t w, uint32_t h, std::vector<float>& pool,
+bool build_env_cdfs(const float* img, uint32_t w, uint32_t h, std::vector<float>& pool,
                     uint64_t& row_off, uint64_t& col_off) {
+  if (g_cdf_builder) {
+    const size_t base = pool.size();
+    row_off = base;
+    col_off = base + (h + 1);
+    pool.resize(base + (h + 1) + static_cast<size_t>(h) * (w + 1));
+    if (g_cdf_builder(img, w, h, pool.data() + row_off, pool.data() + col_off) == 0) return true;
+    pool.resize(base);
+    host_set_error("the installed env-map CDF builder failed");
+    return false;
+  }
   std::vector<float> lum(static_cast<size_t>(w) * h);
   for (size_t y = 0; y < h; ++y) {
     float v = (static_cast<float>(y) + 0.5f) / static_cast<float>(h);
@@ -149,4 +190,36 @@ void build_env_cdfs(const float* img, uint32_t w, uint32_t h, std::vector<float>
   for (size_t y = 0; y < h; ++y)
     row_int[y] = build_cdf1d(lum.data() + y * w, w, pool.data() + col_off + y * (w + 1));
   build_cdf1d(row_int.data(), h, pool.data() + row_off);
+  return true;
+}
+
+// ---- 8-bit image conversions of the reference's texture loaders ------------------------------
+// convert_sRGB_to_linear (src/image_texture.cpp:257-263, include/color_utils.h:28-47): value/255,
+// then the sRGB EOTF; a function of the 256 possible inputs
+extern "C" void vimg_host_srgb8_lut(float lut[256]) {
+  for (int i = 0; i < 256; ++i) {
+    float p = static_cast<float>(i) / 255.f;
+    lut[i] = (p <= 0.04045f) ? p / 12.92f : std::pow((p + 0.055f) / 1.055f, 2.4f);
+  }
+}
+extern "C" void vimg_host_srgb8_to_linear(const uint8_t* in, uint64_t n, float* out) {
+  float lut[256];
+  vimg_host_srgb8_lut(lut);
+#pragma omp parallel for
+  for (int64_t i = 0; i < static_cast<int64_t>(n); ++i) out[i] = lut[in[i]];
+}
+// convert_RGB_to_normal (src/image_texture.cpp:265-275)
+extern "C" void vimg_host_rgb8_to_normal(const uint8_t* rgb8, uint64_t n_pixels, float scale, float* out) {
+#pragma omp parallel for
+  for (int64_t i = 0; i < static_cast<int64_t>(n_pixels); ++i) {
+    float x = static_cast<float>(rgb8[i * 3 + 0]) / 127.5f - 1.f;
+    float y = static_cast<float>(rgb8[i * 3 + 1]) / 127.5f - 1.f;
+    float z = static_cast<float>(rgb8[i * 3 + 2]) / 127.5f - 1.f;
+    x *= scale;
+    y *= scale;
+    const float inv = 1.0f / std::sqrt(x * x + y * y + z * z);   // glm::normalize
+    out[i * 3 + 0] = x * inv;
+    out[i * 3 + 1] = y * inv;
+    out[i * 3 + 2] = z * inv;
+  }
 }
