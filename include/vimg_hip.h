@@ -75,6 +75,13 @@ int vimg_hip_render_to_host(VimgDeviceScene* scene, const VimgRenderParams* para
 int vimg_hip_trace_pixel(VimgDeviceScene* scene, const VimgRenderParams* params, int x, int y,
                          float* out_rgb_host);
 
+/* heatmap_img (reference src/integrators/heatmap.cpp:38-147, called from src/main.cpp:255): the
+ * BVH traversal-cost picture, turbo(colour) of cost / factor (factor <= 0 -> 20).  Uses
+ * params->samples and the tile shard; the output layout is vimg_hip_render's.  d_out_rgb: device
+ * pointer.  Blocking. */
+int vimg_hip_render_heatmap(VimgDeviceScene* scene, const VimgRenderParams* params, float factor,
+                            void* d_out_rgb, void* stream);
+
 /* De-interleaves `world` gathered compact shard buffers (concatenated in rank order, each
  * padded to `shard_stride_pixels` triples) into the reference image layout.  d_shards and
  * d_out_rgb are DEVICE pointers. */

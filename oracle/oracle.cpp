@@ -719,6 +719,76 @@ bool bvh_hit(const Ctx& c, Ray& ray, HitInfo* out) {
   return false;
 }
 
+// BVH::hit<float> — reference include/bvh.h:83-225 with T = float, scalar slab path: the cost of
+// one closest-hit style traversal (root test 0.5, a pair of sibling boxes 2 x 0.5 (:189-192), a
+// primitive test 1 (:160-162); hit_check shortens ray.maxT as it goes).
+float bvh_cost(const Ctx& c, Ray& ray) {
+  const VimgScene* s = c.s;
+  const VimgBVH& bvh = s->bvh;
+  const float intersection_cost = 1.f, traversal_cost = 0.5f;   // BVHConst, bvh.h:17-20
+  float return_variable = 0.f;
+  if (bvh.num_nodes == 0) return return_variable;
+  vec3 inv{1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z};
+  const float* bb = bvh.bb_mins_maxes;
+  float root_hit = slab_intersect_aabb_array(ray, inv, bb + 0, bb + 6);
+  return_variable += traversal_cost;
+  if (std::isinf(root_hit)) return return_variable;
+  uint32_t stack[128];
+  int sp = 0;
+  stack[sp++] = 0;
+  while (sp > 0) {
+    const VimgBVHNode& node = bvh.nodes[stack[--sp]];
+    if (node.obj_count != 0) {
+      for (uint32_t i = 0; i < node.obj_count; ++i) {
+        uint32_t prim_index = bvh.obj_indices[node.first_index + i];
+        const VimgPrim& p = s->prims[prim_index];
+        ForHitInfo tmp{0.f, 0.f, 0.f, 0.f, prim_index, true};
+        if (p.type == VIMG_PRIM_TRIANGLE) tri_hit(s, p.index, ray, &tmp);
+        else sphere_hit(s->spheres[p.index], ray);
+        return_variable += intersection_cost;
+      }
+    } else {
+      uint32_t first_child = node.first_index;
+      uint32_t sec_child = first_child + 1;
+      size_t l_min = size_t{first_child} * 2 + 2, l_max = l_min + 2;
+      size_t r_min = l_min + 1, r_max = l_max + 1;
+      float bb_hit1 = slab_intersect_aabb_array(ray, inv, bb + 3 * l_min, bb + 3 * l_max);
+      float bb_hit2 = slab_intersect_aabb_array(ray, inv, bb + 3 * r_min, bb + 3 * r_max);
+      return_variable += traversal_cost * 2.f;
+      if (!std::isinf(bb_hit2)) {
+        if (!std::isinf(bb_hit1)) {
+          if (bb_hit2 > bb_hit1) std::swap(first_child, sec_child);
+          stack[sp++] = first_child;
+        }
+        stack[sp++] = sec_child;
+      } else if (!std::isinf(bb_hit1)) {
+        stack[sp++] = first_child;
+      }
+    }
+  }
+  return return_variable;
+}
+
+// turbo_colormap — reference src/integrators/heatmap.cpp:21-36; glm::dot of vec4 is
+// (x + y) + (z + w) of the products, of vec2 x + y (glm 1.0.1 detail/func_geometric.inl)
+vec3 turbo_colormap(float x) {
+  const float kR4[4] = {static_cast<float>(0.13572138), static_cast<float>(4.61539260),
+                        static_cast<float>(-42.66032258), static_cast<float>(132.13108234)};
+  const float kG4[4] = {static_cast<float>(0.09140261), static_cast<float>(2.19418839),
+                        static_cast<float>(4.84296658), static_cast<float>(-14.18503333)};
+  const float kB4[4] = {static_cast<float>(0.10667330), static_cast<float>(12.64194608),
+                        static_cast<float>(-60.58204836), static_cast<float>(110.36276771)};
+  const float kR2[2] = {static_cast<float>(-152.94239396), static_cast<float>(59.28637943)};
+  const float kG2[2] = {static_cast<float>(4.27729857), static_cast<float>(2.82956604)};
+  const float kB2[2] = {static_cast<float>(-89.90310912), static_cast<float>(27.34824973)};
+  x = clampf(x, 0.f, 1.f);
+  const float v4[4] = {1.0f, x, x * x, x * x * x};
+  const float v2[2] = {v4[2] * v4[2], v4[3] * v4[2]};
+  auto dot4 = [&](const float* k) { return (v4[0] * k[0] + v4[1] * k[1]) + (v4[2] * k[2] + v4[3] * k[3]); };
+  auto dot2 = [&](const float* k) { return v2[0] * k[0] + v2[1] * k[1]; };
+  return vec3{dot4(kR4) + dot2(kR2), dot4(kG4) + dot2(kG2), dot4(kB4) + dot2(kB2)};
+}
+
 // ============================================================================ materials
 inline bool mat_is_emissive(const VimgMaterial& m) { return m.type == VIMG_MAT_DIFFUSE_LIGHT; }
 // is_delta: base true (material.h:71), Lambertian/DiffuseLight/Principled false, Dielectric true
@@ -1798,6 +1868,55 @@ int oracle_render(const VimgScene* scene, const VimgRenderParams* params, int nu
     for (const Tile& tl : work) px += uint64_t{tl.x1 - tl.x0 + 1} * (tl.y1 - tl.y0 + 1);
     stats->paths = px * params->samples;
   }
+  return static_cast<int>(cores);
+}
+
+// heatmap_img — reference src/integrators/heatmap.cpp:38-147.  Per pixel: the traversal cost of
+// its camera rays summed over the samples, averaged, truncated to uint32, colour-mapped with
+// turbo(value / factor) (factor <= 0 -> 20).  out_counts (optional, test hook): the truncated
+// averages before the colour map.
+int oracle_heatmap(const VimgScene* scene, const VimgRenderParams* params, float factor,
+                   int num_threads, float* out_rgb, float* out_counts) {
+  if (!params_ok(scene, params) || !out_rgb) return -1;
+  const uint32_t W = scene->camera.res_x, H = scene->camera.res_y;
+  const unsigned cores
+      = num_threads > 0 ? num_threads : std::max(1u, std::thread::hardware_concurrency());
+  if (factor <= 0) factor = 20.f;
+  std::vector<std::thread> workers;
+  for (unsigned t = 0; t < cores; ++t) {
+    workers.emplace_back([&, t]() {
+      Ctx c = make_ctx(scene, nullptr);
+      uint32_t tile_id = 0, mine = 0;
+      for (uint32_t x0 = 0; x0 < W; x0 += 8)
+        for (uint32_t y0 = 0; y0 < H; y0 += 8, ++tile_id) {
+          if (tile_id % params->tile_world != params->tile_rank) continue;
+          if (mine++ % cores != t) continue;
+          for (size_t y = y0; y <= std::min(y0 + 7, H - 1); y++)
+            for (size_t x = x0; x <= std::min(x0 + 7, W - 1); x++) {
+              float pixel_hit_accumulator = 0.f;
+              size_t image_index = x + ((H - 1 - y) * size_t{W});
+              size_t image_seq_start = x + y;
+              Pcg rng;
+              pcg32_srandom_r(&rng, image_index, 0);
+              for (size_t smp = 0; smp < params->samples; smp++) {
+                vec2 off = random_x_y_r2(static_cast<uint32_t>(image_seq_start + smp));
+                float rand2 = rand_float(rng);   // Q4: right-to-left argument evaluation
+                float rand1 = rand_float(rng);
+                Ray cam_ray = generate_ray(c, x + off.x, y + off.y, rand1, rand2);
+                pixel_hit_accumulator += bvh_cost(c, cam_ray);
+              }
+              float v = static_cast<float>(
+                  static_cast<uint32_t>(pixel_hit_accumulator / static_cast<float>(params->samples)));
+              if (out_counts) out_counts[image_index] = v;
+              vec3 col = turbo_colormap(v / factor);
+              out_rgb[image_index * 3 + 0] = col.x;
+              out_rgb[image_index * 3 + 1] = col.y;
+              out_rgb[image_index * 3 + 2] = col.z;
+            }
+        }
+    });
+  }
+  for (auto& th : workers) th.join();
   return static_cast<int>(cores);
 }
 

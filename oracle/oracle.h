@@ -29,6 +29,12 @@ extern "C" {
 int oracle_render(const VimgScene* scene, const VimgRenderParams* params, int num_threads,
                   float* out_rgb, VimgRenderStats* stats);
 
+/* heatmap_img (reference src/integrators/heatmap.cpp:38-147; BVH::hit<float>, include/bvh.h:83-225):
+ * turbo colour map of the per-pixel BVH traversal cost.  out_counts (optional): W*H truncated
+ * averages before the colour map.  Same layout and sharding as oracle_render. */
+int oracle_heatmap(const VimgScene* scene, const VimgRenderParams* params, float factor,
+                   int num_threads, float* out_rgb, float* out_counts);
+
 /* trace_pixel (reference include/integrators.h:181-220) */
 int oracle_trace_pixel(const VimgScene* scene, const VimgRenderParams* params, int x, int y,
                        float* out_rgb3);

@@ -39,6 +39,8 @@ def load(name="liboracle.so"):
         lib.oracle_probe.restype = C.c_int
         lib.oracle_probe.argtypes = [abi.PScene, C.c_int, C.c_int, abi.Pf32, abi.Pf32]
         lib.oracle_uses_float_libm.restype = C.c_int
+        lib.oracle_heatmap.restype = C.c_int
+        lib.oracle_heatmap.argtypes = [abi.PScene, abi.PParams, C.c_float, C.c_int, abi.Pf32, abi.Pf32]
         lib.oracle_post_rgb8.restype = C.c_int
         lib.oracle_post_rgb8.argtypes = [abi.Pf32, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
         _libs[name] = lib
@@ -56,6 +58,18 @@ def render(scene, params, threads=0, lib=None):
     if used < 0:
         raise RuntimeError("oracle_render rejected its arguments")
     return out, stats, used
+
+
+def heatmap(scene, params, factor=-1.0, threads=0, lib=None):
+    """Returns (turbo image [H,W,3], truncated per-pixel average cost [H,W])."""
+    lib = lib or load()
+    w, h = scene.resolution
+    out = np.zeros((h, w, 3), dtype=np.float32)
+    counts = np.zeros((h, w), dtype=np.float32)
+    if lib.oracle_heatmap(scene.view, C.byref(params), factor, threads,
+                          out.ctypes.data_as(abi.Pf32), counts.ctypes.data_as(abi.Pf32)) < 0:
+        raise RuntimeError("oracle_heatmap rejected its arguments")
+    return out, counts
 
 
 def trace_pixel(scene, params, x, y, lib=None):

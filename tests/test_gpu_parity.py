@@ -539,3 +539,37 @@ def test_precompute_8bit_conversions_and_render_with_gpu_built_tables():
     a, _ = _dev(ref).render_to_host(p)
     b, _ = _dev(dev).render_to_host(p)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+# ------------------------------------------------------------------ heatmap integrator (8f rank 2)
+@pytest.mark.parametrize("scene_name,bvh", [("disney_spheres.json", "sweep"), ("glass_in_box.json", "binned"),
+                                            ("feature", "sweep"), ("config4", "sweep")])
+def test_heatmap_matches_oracle_bit_for_bit(scene_name, bvh):
+    """vimg_hip_render_heatmap (reference heatmap_img + BVH::hit<float>): the cost is an integer
+    count of node visits and primitive tests and the colour map is plain float arithmetic, so the
+    picture is bit-identical; whole image and 3 shards."""
+    from vimg_amd import abi, dist as vdist
+    if scene_name == "feature":
+        s = scenes.feature_scene(res=(72, 40), envmap=False, lens=True)
+    elif scene_name == "config4":
+        s = scenes.config4_scene(res=(96, 54), n_lat=48, env=(128, 64))
+    else:
+        s = scenes.json_scene(scene_name, res=(100, 60),
+                              bvh=abi.BVH_SWEEP if bvh == "sweep" else abi.BVH_BINNED)
+    p = s.default_params(samples=4)
+    d = _dev(s)
+    for factor in (-1.0, 7.5):
+        cpu, counts = O.heatmap(s, p, factor=factor)
+        gpu = d.render_heatmap(p, factor).cpu().numpy()
+        assert np.array_equal(gpu.view(np.uint32), cpu.view(np.uint32)), scene_name
+    assert counts.max() > 0
+    w, h = s.resolution
+    slabs = []
+    for r in range(3):
+        pr = s.default_params(samples=4, tile_rank=r, tile_world=3)
+        slabs.append(d.render_heatmap(pr, 7.5).cpu().numpy())
+    stride = max(x.shape[0] for x in slabs)
+    padded = np.zeros((3, stride, 3), dtype=np.float32)
+    for r, x in enumerate(slabs):
+        padded[r, :x.shape[0]] = x
+    assert np.array_equal(vdist.assemble_numpy(padded, w, h, 3), gpu)

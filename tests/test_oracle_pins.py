@@ -330,3 +330,37 @@ def test_post_chain_restatement():
         a = O.post_rgb8(hdr, tm).astype(int)
         b = vimg_amd.tonemap_to_rgb8(hdr, tm).astype(int)
         assert np.abs(a - b).max() <= 1 and (a == b).mean() > 0.999
+
+
+def test_heatmap_cost_counts_the_same_events_as_the_render_statistics():
+    """heatmap_img / BVH::hit<float> (reference src/integrators/heatmap.cpp, include/bvh.h:128-131,
+    160-162,189-192): at 1 spp the truncated per-pixel cost is (internal node visits + primitive
+    tests) of the pixel's camera ray - the 0.5 of the root test is what the truncation drops - and
+    the shading-normal integrator traces exactly those camera rays (same RNG draws), so the sum
+    over the image equals its event counters.  A pixel whose ray misses the root box costs 0.5 ->
+    0 -> turbo(0), the colour map's constant term."""
+    s = scenes.json_scene("cornell_box_spheres.json", res=(64, 48))
+    p = s.default_params(samples=1, integrator="s_normal")
+    img, counts = O.heatmap(s, p, factor=20.0, threads=2)
+    _, st, _ = O.render(s, p, threads=2)
+    assert counts.sum() == st.internal_visits + st.prim_tests
+    assert np.all(counts == np.floor(counts)) and counts.max() < 200
+    # turbo(x) at the ends of its clamp and one interior point (coefficients of the published map)
+    k = np.float32
+    zero = np.array([0.13572138, 0.09140261, 0.10667330], dtype=k)
+    far = scenes.json_scene("MIS_light_tests/sphere_light_small_mis.json", res=(32, 32))
+    img2, counts2 = O.heatmap(far, far.default_params(samples=4), factor=1e9)
+    assert np.allclose(img2.reshape(-1, 3), zero, atol=1e-6)          # cost / 1e9 -> 0
+    img3, _ = O.heatmap(s, p, factor=1e-9)                            # everything saturates to x = 1
+    sat = img3[counts > 0]
+    one = np.array([0.13572138 + 4.61539260 - 42.66032258 + 132.13108234 - 152.94239396 + 59.28637943,
+                    0.09140261 + 2.19418839 + 4.84296658 - 14.18503333 + 4.27729857 + 2.82956604,
+                    0.10667330 + 12.64194608 - 60.58204836 + 110.36276771 - 89.90310912 + 27.34824973])
+    assert np.allclose(sat, one, atol=2e-4)
+    # sharding covers the image exactly once
+    parts = np.zeros_like(img)
+    for r in range(3):
+        pr = s.default_params(samples=1, integrator="s_normal", tile_rank=r, tile_world=3)
+        part, _ = O.heatmap(s, pr, factor=20.0)
+        parts += part
+    assert np.array_equal(parts, img)

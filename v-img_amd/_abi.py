@@ -172,6 +172,7 @@ HIP_SYMBOLS = {
     "vimg_hip_render_async": (C.c_int, [C.c_void_p, PParams, C.c_void_p, C.c_void_p]),
     "vimg_hip_render_to_host": (C.c_int, [C.c_void_p, PParams, Pf32, PStats]),
     "vimg_hip_trace_pixel": (C.c_int, [C.c_void_p, PParams, C.c_int, C.c_int, Pf32]),
+    "vimg_hip_render_heatmap": (C.c_int, [C.c_void_p, PParams, f32, C.c_void_p, C.c_void_p]),
     "vimg_hip_assemble_shards": (C.c_int, [C.c_void_p, u32, i64, C.c_void_p, C.c_void_p,
                                            C.c_void_p]),
     "vimg_hip_time_renders": (C.c_int, [C.c_void_p, PParams, C.c_void_p, C.c_int, Pf32]),

@@ -1,7 +1,8 @@
 // vimg-amd: the C++ host program around the GPU hot path — the counterpart of the reference's
 // main (src/main.cpp:38-377) with its flags: -f scene.json, -t threads (ignored: the render runs
 // on the GPU), -c tonemapper 0-3 (clamp, AgX, Reinhard, ACES; default AgX as main.cpp:97-114),
-// -d "x y" single-pixel trace, -b 0 binned / 1 sweep BVH (default 0 as main.cpp:183-187), plus
+// -d "x y" single-pixel trace, -b 0 binned / 1 sweep BVH (default 0 as main.cpp:183-187),
+// -m factor heatmap mode (BVH traversal cost, main.cpp:62-65,98-100,250-256), plus
 // -s spp override and -o output path.  Scene loading, the SAH BVH build and PNG writing happen
 // here on the host (libvimg_host); the render and the post chain go through the C ABI of
 // libvimg_hip.
@@ -25,6 +26,7 @@ int main(int argc, char** argv) {
   std::string scene_path, out_path = "v_img_amd.png";
   int tonemapper = 1, bvh_type = VIMG_BVH_BINNED, px = -1, py = -1;
   long spp_override = -1;
+  float heatmap_max = -1.f;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto next = [&]() -> const char* { return (i + 1 < argc) ? argv[++i] : ""; };
@@ -33,6 +35,7 @@ int main(int argc, char** argv) {
     else if (a == "-c") tonemapper = std::atoi(next());
     else if (a == "-b") bvh_type = std::atoi(next()) == 1 ? VIMG_BVH_SWEEP : VIMG_BVH_BINNED;
     else if (a == "-s") spp_override = std::atol(next());
+    else if (a == "-m") heatmap_max = static_cast<float>(std::atof(next()));
     else if (a == "-o") out_path = next();
     else if (a == "-d") {
       if (std::sscanf(next(), "%d %d", &px, &py) != 2) {
@@ -40,7 +43,7 @@ int main(int argc, char** argv) {
         return 2;
       }
     } else {
-      std::fprintf(stderr, "usage: vimg-amd -f scene.json [-c 0..3] [-b 0|1] [-s spp] [-d \"x y\"] [-o out.png]\n");
+      std::fprintf(stderr, "usage: vimg-amd -f scene.json [-c 0..3] [-b 0|1] [-m factor] [-s spp] [-d \"x y\"] [-o out.png]\n");
       return 2;
     }
   }
@@ -70,7 +73,10 @@ int main(int argc, char** argv) {
   vimg_host_default_params(hs, &params);
   if (spp_override > 0) params.samples = static_cast<uint32_t>(spp_override);
   // main forces 4 spp and the clamp tonemapper for the normal integrators (src/main.cpp:220-237)
-  if (params.integrator == VIMG_INTEGRATOR_S_NORMAL || params.integrator == VIMG_INTEGRATOR_G_NORMAL) {
+  // ... and for the heatmap (src/main.cpp:250-254)
+  const bool heatmap = heatmap_max >= 0.f && px < 0;
+  if (heatmap || params.integrator == VIMG_INTEGRATOR_S_NORMAL ||
+      params.integrator == VIMG_INTEGRATOR_G_NORMAL) {
     if (spp_override <= 0) params.samples = 4;
     tonemapper = 0;
   }
@@ -102,15 +108,25 @@ int main(int argc, char** argv) {
   }
   VimgRenderStats st;
   double t3 = now_s();
-  if (vimg_hip_render(dev, &params, d_rgb, nullptr, &st) != VIMG_OK) {
-    std::fprintf(stderr, "render failed: %s\n", vimg_hip_last_error());
-    return 1;
+  if (heatmap) {
+    std::printf("Creating Heatmap for ray intersection\nHeatmap factor set to %g\n",
+                heatmap_max <= 0 ? 20.0 : double(heatmap_max));
+    if (vimg_hip_render_heatmap(dev, &params, heatmap_max, d_rgb, nullptr) != VIMG_OK) {
+      std::fprintf(stderr, "heatmap failed: %s\n", vimg_hip_last_error());
+      return 1;
+    }
+    std::printf("image rendering %.3f s\n", now_s() - t3);
+  } else {
+    if (vimg_hip_render(dev, &params, d_rgb, nullptr, &st) != VIMG_OK) {
+      std::fprintf(stderr, "render failed: %s\n", vimg_hip_last_error());
+      return 1;
+    }
+    double t4 = now_s();
+    const double rays = double(st.closest_rays + st.shadow_rays);
+    std::printf("image rendering %.3f s: %.1f Mrays/s (%.4f rays per camera path), %llu NaN samples\n",
+                t4 - t3, rays / (t4 - t3) / 1e6, rays / double(st.paths),
+                static_cast<unsigned long long>(st.nan_samples));
   }
-  double t4 = now_s();
-  const double rays = double(st.closest_rays + st.shadow_rays);
-  std::printf("image rendering %.3f s: %.1f Mrays/s (%.4f rays per camera path), %llu NaN samples\n",
-              t4 - t3, rays / (t4 - t3) / 1e6, rays / double(st.paths),
-              static_cast<unsigned long long>(st.nan_samples));
   if (vimg_hip_post_rgb8(d_rgb, W, H, tonemapper, d_rgb8, nullptr) != VIMG_OK) {
     std::fprintf(stderr, "post failed: %s\n", vimg_hip_last_error());
     return 1;

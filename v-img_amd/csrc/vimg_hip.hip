@@ -18,6 +18,7 @@
 #include "pre_kernels.h"
 #include "render_kernels.h"
 #include "render_pool_kernel.h"
+#include "heatmap_kernel.h"
 
 using namespace vimg;
 
@@ -675,6 +676,28 @@ int vimg_hip_render(VimgDeviceScene* s, const VimgRenderParams* p, void* d_out, 
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(st));
   if (stats) return fetch_stats(s, p, stats);
+  return VIMG_OK;
+}
+
+// heatmap_img (reference src/integrators/heatmap.cpp:38-147) behind the same boundary: the
+// integrator field of the parameters is not used, samples and the tile shard are.
+int vimg_hip_render_heatmap(VimgDeviceScene* s, const VimgRenderParams* p, float factor, void* d_out,
+                            void* stream) {
+  int rc = check_params(s, p);
+  if (rc) return rc;
+  if (!d_out) return fail(VIMG_E_INVALID, "null output pointer");
+  if (factor <= 0) factor = 20.f;   // heatmap.cpp:137-139
+  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : g_stream;
+  LaunchCfg c = make_launch(s, p, -1, -1, false);
+  if (c.args.num_local_tiles == 0) return VIMG_OK;
+  if (c.lds_bytes > 48u * 1024u)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(heatmap_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(c.lds_bytes)));
+  const uint32_t grid = (c.args.num_local_tiles * 64u + 255u) / 256u;
+  hipLaunchKernelGGL(heatmap_kernel, dim3(grid), dim3(256), c.lds_bytes, st, s->d, c.args, factor,
+                     static_cast<float*>(d_out));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));
   return VIMG_OK;
 }
 

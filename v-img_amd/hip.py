@@ -89,6 +89,21 @@ class DeviceScene:
                                                  C.byref(st) if stats else None))
         return (out, st) if stats else out
 
+    def render_heatmap(self, params, factor=-1.0, out=None, stream=None):
+        """BVH traversal-cost picture (reference heatmap_img) into a torch CUDA tensor [H, W, 3]
+        (or the compact shard slab when params.tile_world > 1)."""
+        import torch
+        w, h = self.resolution
+        if out is None:
+            n = w * h if params.tile_world == 1 else self.shard_pixels(params)
+            out = torch.empty((n, 3), dtype=torch.float32, device="cuda")
+            if params.tile_world == 1:
+                out = out.view(h, w, 3)
+        sp = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        _check(self._lib.vimg_hip_render_heatmap(self._h, C.byref(params), factor,
+                                                 C.c_void_p(out.data_ptr()), sp))
+        return out
+
     def trace_pixel(self, params, x, y):
         out = np.zeros(3, dtype=np.float32)
         _check(self._lib.vimg_hip_trace_pixel(self._h, C.byref(params), x, y,
