@@ -125,6 +125,70 @@ def test_json_loader_errors_and_defaults():
 
 
 # ------------------------------------------------------------------------------- BVH builders
+def test_json_mesh_surface_loads_obj_positions_and_fans_polygons(tmp_path):
+    """"type": "mesh" (reference src/scene_loading/json_scene.cpp:366-385 + load_from_obj,
+    src/geometry/mesh_loading.cpp:21-65): positions only, path relative to the scene file, every
+    face a fan, 1-based / negative indices, v/vt/vn tokens; the transform is applied to positions."""
+    (tmp_path / "assets").mkdir()
+    (tmp_path / "scenes").mkdir()
+    obj = """# unit cube
+v -0.5 -0.5 -0.5
+v  0.5 -0.5 -0.5
+v  0.5  0.5 -0.5
+v -0.5  0.5 -0.5
+v -0.5 -0.5  0.5
+v  0.5 -0.5  0.5
+v  0.5  0.5  0.5
+v -0.5  0.5  0.5
+vn 0 0 1
+vt 0 0
+f 1 4 3 2
+f 5/1/1 6/1/1 7/1/1 8/1/1
+f -8 -7 -3 -4
+f 2//1 3//1 7//1 6//1
+f 3 4 8 7
+f 4 1 5
+f 4 5 8
+"""
+    (tmp_path / "assets" / "cube.obj").write_text(obj)
+    scene = {
+        "camera": {"transform": {"from": [3, 2, 5], "at": [0, 0, 0], "up": [0, 1, 0]}, "vfov": 30,
+                   "resolution": [32, 24]},
+        "sampler": {"samples": 2, "depth": 3},
+        "integrator": {"type": "mis"},
+        "materials": [{"type": "lambertian", "name": "m", "texture": {"type": "constant", "albedo": [0.8, 0.8, 0.8]}},
+                      {"type": "diffuse_light", "name": "l", "albedo": [3, 3, 3]}],
+        "surfaces": [{"type": "mesh", "filename": "../assets/cube.obj", "mat_name": "m",
+                      "transform": [{"translate": [0, 0.5, 0]}, {"scale": [1, 9, 4]}]},
+                     {"type": "quad", "mat_name": "l", "transform": [{"translate": [0, 0, 9]}]}],
+    }
+    path = tmp_path / "scenes" / "s.json"
+    path.write_text(json.dumps(scene))
+    s = host.HostScene.from_json(str(path))
+    v = s.view.contents
+    assert v.num_meshes == 2 and v.num_prims == 12 + 2
+    m = v.meshes[0]
+    assert (m.num_vertices, m.has_normals, m.num_uv_sets, m.color_tex_uv) == (8, 0, 0, abi.NO_UV)
+    verts = np.ctypeslib.as_array(v.vertices, (v.num_vertices, 3))[:8]
+    want = np.array([[-.5, -.5, -.5], [.5, -.5, -.5], [.5, .5, -.5], [-.5, .5, -.5], [-.5, -.5, .5],
+                     [.5, -.5, .5], [.5, .5, .5], [-.5, .5, .5]], dtype=np.float32)
+    want = (want + np.float32([0, 0.5, 0])) * np.float32([1, 9, 4])     # translate, then scale
+    assert np.array_equal(verts, want)
+    tri = np.ctypeslib.as_array(v.tri_indices, (v.num_tris, 3))[:12]
+    assert tri.tolist() == [[0, 3, 2], [0, 2, 1], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4],
+                            [1, 2, 6], [1, 6, 5], [2, 3, 7], [2, 7, 6], [3, 0, 4], [3, 4, 7]]
+    # errors: missing file, face before its vertices
+    scene["surfaces"][0]["filename"] = "nope.obj"
+    path.write_text(json.dumps(scene))
+    with pytest.raises(host.HostError, match="cannot open"):
+        host.HostScene.from_json(str(path))
+    (tmp_path / "scenes" / "bad.obj").write_text("v 0 0 0\nf 1 2 3\n")
+    scene["surfaces"][0]["filename"] = "bad.obj"
+    path.write_text(json.dumps(scene))
+    with pytest.raises(host.HostError, match="not defined"):
+        host.HostScene.from_json(str(path))
+
+
 @pytest.mark.parametrize("kind", [abi.BVH_SWEEP, abi.BVH_BINNED])
 def test_bvh_invariants(kind):
     s = scenes.big_mesh_scene()

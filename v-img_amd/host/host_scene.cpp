@@ -150,6 +150,59 @@ int add_quad_impl(VimgHostScene& s, const M4& xform, uint32_t material) {
                        VIMG_NO_UV);
 }
 
+// load_from_obj, reference src/geometry/mesh_loading.cpp:21-65: positions only ("v" lines,
+// transformed by the surface transform with the perspective divide) and the triangles of every
+// face ("f" lines: vertex index before the first '/', 1-based or negative = relative to the end;
+// polygons are split into a fan, which is what tinyobjloader's default triangulation does with
+// the convex polygons it is fed here).  Normals and texture coordinates of the file are ignored,
+// as in the reference; the mesh goes through the legacy Mesh ctor with no uv set
+// (include/geometry/mesh.h:33-41).
+int add_obj_mesh(VimgHostScene& s, const std::string& path, const M4& xform, uint32_t material) {
+  std::ifstream f(path);
+  if (!f) {
+    g_err = "Tinyobj failed to load the mesh: cannot open " + path;
+    return -1;
+  }
+  std::vector<float> verts;
+  std::vector<uint32_t> idx;
+  std::vector<long> face;
+  std::string line;
+  while (std::getline(f, line)) {
+    std::istringstream ls(line);
+    std::string tag;
+    if (!(ls >> tag)) continue;
+    if (tag == "v") {
+      V3 p{0, 0, 0};
+      ls >> p.x >> p.y >> p.z;
+      V3 q = hm::xform_point(xform, p);
+      verts.insert(verts.end(), {q.x, q.y, q.z});
+    } else if (tag == "f") {
+      face.clear();
+      std::string tok;
+      const long nv = static_cast<long>(verts.size() / 3);
+      while (ls >> tok) {
+        long vi = std::strtol(tok.c_str(), nullptr, 10);   // stops at the first '/'
+        if (vi < 0) vi = nv + vi; else vi -= 1;
+        if (vi < 0 || vi >= nv) {
+          g_err = "obj face refers to a vertex that is not defined yet: " + path;
+          return -1;
+        }
+        face.push_back(vi);
+      }
+      for (size_t k = 2; k < face.size(); ++k)
+        idx.insert(idx.end(), {static_cast<uint32_t>(face[0]), static_cast<uint32_t>(face[k - 1]),
+                               static_cast<uint32_t>(face[k])});
+    }
+  }
+  if (idx.empty()) {
+    g_err = "obj file has no faces: " + path;
+    return -1;
+  }
+  return add_mesh_impl(s, static_cast<uint32_t>(verts.size() / 3), verts.data(), nullptr, 0, nullptr,
+                       static_cast<uint32_t>(idx.size() / 3), idx.data(), material, VIMG_NO_UV,
+                       VIMG_NO_UV, VIMG_NO_UV);
+}
+
 V3 json_vec3(const jmini::Value& v) {
   return V3{v.at(size_t{0}).as_float(), v.at(size_t{1}).as_float(), v.at(size_t{2}).as_float()};
 }
@@ -226,7 +279,7 @@ VimgMaterial blank_material(uint32_t type) {
   return m;
 }
 
-void load_json(VimgHostScene& s, const std::string& text) {
+void load_json(VimgHostScene& s, const std::string& text, const std::string& scene_dir) {
   jmini::Value root = jmini::Parser(text).parse();
 
   // ---- set_integrator_data, reference json_scene.cpp:155-231
@@ -329,22 +382,24 @@ void load_json(VimgHostScene& s, const std::string& text) {
         s.lights.push_back(
             VimgLight{VIMG_LIGHT_PRIM, static_cast<uint32_t>(s.prims.size() - 1)});
     } else if (type == "mesh") {
-      throw std::runtime_error("surface type 'mesh' (.obj files) is loaded by the host "
-                               "application; use vimg_host_add_mesh");
+      // json_scene.cpp:366-385: the .obj path is relative to the scene file's directory
+      const std::string rel = sd.at("filename").as_string();
+      const std::string path = (!rel.empty() && rel[0] == '/') ? rel : scene_dir + rel;
+      if (add_obj_mesh(s, path, xform, mat) < 0) throw std::runtime_error(g_err);
     } else {
       throw std::runtime_error("Unknown surface " + type);
     }
   }
 }
 
-int from_text(const std::string& text, VimgHostScene** out) {
+int from_text(const std::string& text, VimgHostScene** out, const std::string& scene_dir = "") {
   if (!out) {
     host_set_error("null output pointer");
     return -1;
   }
   auto* s = new VimgHostScene();
   try {
-    load_json(*s, text);
+    load_json(*s, text, scene_dir);
   } catch (const std::exception& e) {
     host_set_error(e.what());
     delete s;
@@ -366,7 +421,10 @@ int vimg_host_scene_from_json_file(const char* path, VimgHostScene** out) {
   }
   std::stringstream ss;
   ss << f.rdbuf();
-  return from_text(ss.str(), out);
+  std::string dir(path);
+  const size_t slash = dir.find_last_of('/');
+  dir = (slash == std::string::npos) ? std::string() : dir.substr(0, slash + 1);
+  return from_text(ss.str(), out, dir);
 }
 
 int vimg_host_scene_from_json_text(const char* text, VimgHostScene** out) {
