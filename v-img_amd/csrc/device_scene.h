@@ -128,11 +128,11 @@ struct DeviceStats {
   unsigned long long trip_descend, trip_prim, iterations;   // wave-level loop trips (diagnostic)
   // -DVIMG_PROFILE builds only (make prof): s_memtime cycles of wave 0.. summed over waves, per
   // stage of render_pool_kernel, and lanes switched on per vertex batch
-  unsigned long long prof[24];
+  unsigned long long prof[28];
 };
 enum : int { PF_TOTAL = 0, PF_V_LOAD, PF_V_LIGHT, PF_V_SAMPLE, PF_V_EVAL, PF_V_FINISH, PF_V_STORE,
              PF_W_REFILL, PF_W_BOX, PF_W_LEAF, PF_W_RETIRE, PF_V_BATCHES, PF_V_LANES, PF_V_ATVERTEX,
              PF_W_ROUNDS, PF_CLS_CYC0, PF_CLS_CYC1, PF_CLS_CYC2, PF_CLS_CYC3, PF_CLS_LANES0, PF_CLS_LANES1,
-             PF_CLS_LANES2, PF_CLS_LANES3, PF_COUNT };
+             PF_CLS_LANES2, PF_CLS_LANES3, PF_DRAIN, PF_MAXWAVE, PF_COUNT };
 
 }  // namespace vimg

@@ -510,7 +510,12 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
           const uint32_t leader = __ffsll(static_cast<long long>(mask)) - 1;
           if (lane == leader) base = atomicAdd(work_counter, cntp);
           base = __shfl(base, leader);
-          if (base >= total_items) pixels_left = false;
+          if (base >= total_items) {
+            pixels_left = false;
+#ifdef VIMG_PROFILE
+            prof_acc[PF_DRAIN] = __builtin_readcyclecounter();   // time stamp: turned into a span at exit
+#endif
+          }
         }
         if (need_pixel) {
           item = pixels_left ? base + lane_rank(mask, lane) : total_items;
@@ -811,8 +816,12 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
 
 #ifdef VIMG_PROFILE
   if (stats && lane == 0) {
-    prof_acc[PF_TOTAL] = __builtin_readcyclecounter() - prof_t0;
-    for (int k = 0; k < PF_COUNT; ++k) atomicAdd(&stats->prof[k], prof_acc[k]);
+    const unsigned long long t_end = __builtin_readcyclecounter();
+    prof_acc[PF_TOTAL] = t_end - prof_t0;
+    prof_acc[PF_DRAIN] = prof_acc[PF_DRAIN] ? t_end - prof_acc[PF_DRAIN] : 0ull;   // after the last pixel fetch
+    for (int k = 0; k < PF_COUNT; ++k)
+      if (k != PF_MAXWAVE) atomicAdd(&stats->prof[k], prof_acc[k]);
+    atomicMax(&stats->prof[PF_MAXWAVE], prof_acc[PF_TOTAL]);
   }
 #endif
   // ---- flush event counts: one atomic per wave and counter

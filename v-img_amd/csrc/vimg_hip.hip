@@ -370,7 +370,8 @@ int fetch_stats(VimgDeviceScene* s, const VimgRenderParams* p, VimgRenderStats* 
                                           "w_box_loop", "w_leaf_loop", "w_retire", "v_batches", "v_lanes",
                                           "v_at_vertex", "w_rounds", "cyc_finisher", "cyc_lambertian",
                                           "cyc_principled", "cyc_other", "lanes_finisher", "lanes_lambertian",
-                                          "lanes_principled", "lanes_other"};
+                                          "lanes_principled", "lanes_other", "drain (after last fetch)",
+                                          "longest wave"};
     for (int k = 0; k < PF_COUNT; ++k)
       std::fprintf(stderr, "[vimg prof] %-24s %14llu  %6.2f %%\n", names[k], ds.prof[k],
                    100.0 * double(ds.prof[k]) / double(ds.prof[PF_TOTAL]));
