@@ -84,16 +84,28 @@ def test_both_render_kernels_give_the_same_bits(scene_name, monkeypatch):
         s = scenes.json_scene(scene_name, res=(136, 72))
         p = s.default_params(samples=12)
     out = {}
-    for pool in ("0", "1"):
-        monkeypatch.setenv("VIMG_HIP_POOL", pool)
+    # "1/5": the pooled kernel with every pixel's samples cut into 5 segments that travel through
+    # per-pixel records in global memory; at this size far more slots are in flight than there
+    # are pixels, so slots constantly draw segments whose predecessor is still running (the
+    # waiting path), often inside the same wave
+    for pool in ("0", "1", "1/5", "1/64"):
+        monkeypatch.setenv("VIMG_HIP_POOL", pool[0])
+        if "/" in pool:
+            monkeypatch.setenv("VIMG_HIP_POOL_SEGMENTS", pool.split("/")[1])
+        else:
+            monkeypatch.delenv("VIMG_HIP_POOL_SEGMENTS", raising=False)
         d = _dev(s)
         img, st = d.render_to_host(p)
+        again, _ = d.render_to_host(p)            # a second launch on the same records (new epoch)
+        assert np.array_equal(img.view(np.uint32), again.view(np.uint32)), pool
         px = d.trace_pixel(p, 17, 23)
         out[pool] = (img, st, px)
     a, b = out["0"], out["1"]
-    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
-    assert np.array_equal(np.asarray(a[2]).view(np.uint32), np.asarray(b[2]).view(np.uint32))
-    assert a[1].as_dict() == b[1].as_dict()
+    for other in ("1", "1/5", "1/64"):
+        o = out[other]
+        assert np.array_equal(a[0].view(np.uint32), o[0].view(np.uint32)), other
+        assert np.array_equal(np.asarray(a[2]).view(np.uint32), np.asarray(o[2]).view(np.uint32)), other
+        assert a[1].as_dict() == o[1].as_dict(), other
     cpu, cst, _ = O.render(s, p)
     _compare_images(b[0], cpu, scene_name + " (pooled kernel)")
     assert b[1].paths == cst.paths

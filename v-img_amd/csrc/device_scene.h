@@ -115,6 +115,10 @@ struct RenderArgs {
   uint32_t lds_nodes;               // number of top-of-tree nodes staged into LDS
   VIMG_GLOBAL v4u* pool_cold;       // pooled kernel: cold slot records, [wave][slot][record] (scene-owned scratch)
   uint32_t lds_leaf;                // pooled kernel: number of leaf records copied to LDS (all or 0)
+  VIMG_GLOBAL v4u* pool_state;      // pooled kernel: per work item {rng lo, rng hi, epoch + segments done, -}{acc.xyz, -}
+  uint32_t pool_segments;           // pooled kernel: segments a pixel's samples are split into (>= 1)
+  uint32_t pool_seg_len;            // pooled kernel: samples per segment
+  uint32_t pool_epoch;              // pooled kernel: tag base of this launch (stale records of earlier launches never match)
   uint32_t pool_slots;              // pooled kernel: path slots per wave (0 = lane-bound kernel)
   uint32_t pool_refill;             // pooled kernel: finished rays that trigger a refill pass
   uint32_t pool_vbatch;             // pooled kernel: queued slots of one class that start a vertex batch

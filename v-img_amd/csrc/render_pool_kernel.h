@@ -23,6 +23,15 @@
 //   * the WALK stage is a persistent while-while loop whose lanes refill from Q_walk the moment
 //     their ray is done (shadow ray first, then the path ray of the same vertex), so the box loop
 //     and the primitive loop keep their lanes busy.
+//   * a pixel is bound to a slot for one SEGMENT of its samples only (an eighth of them): the work
+//     items of the global counter are (segment, pixel) pairs in segment-major order, and between
+//     segments the pixel's state (RNG, accumulator) rests in a per-pixel record in global memory,
+//     published with a release store and picked up with an acquire load by whichever slot draws
+//     the next segment.  A frame then ends with the ragged tail of one segment instead of one
+//     whole pixel (config 2: every wave's last pixels ran 512 samples in a draining pool, a
+//     quarter of the frame at falling efficiency and 10 % spread between waves).  An item whose
+//     predecessor segment is still in flight is not waited for: the slot keeps its claim and
+//     looks again at its next turn;
 // Every path still executes exactly the reference's operations in the reference's order with its
 // own RNG stream, so results are bit-identical to render_kernel and to the oracle.
 #pragma once
@@ -68,6 +77,13 @@ constexpr uint32_t SLOT_IDLE = 0xffffffffu;
 #define PROF_ADD(k, v)
 #endif
 
+// words of a pixel's between-segments record: agent-scope relaxed atomics (global_load/store sc1)
+VD void state_store(VIMG_GLOBAL uint32_t* p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+VD uint32_t state_load(VIMG_GLOBAL uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 VD uint32_t lane_rank(unsigned long long mask, uint32_t lane) {
   return __popcll(mask & ((1ull << lane) - 1ull));
 }
@@ -83,6 +99,9 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
   const uint32_t W = static_cast<uint32_t>(g.res_x), H = static_cast<uint32_t>(g.res_y);
   const bool single = A.single_x >= 0;
   const uint32_t total_items = single ? 1u : A.num_local_tiles * 64u;
+  // work items of the counter: (segment, pixel) in segment-major order
+  const uint32_t n_seg = A.pool_segments, seg_len = A.pool_seg_len;
+  const uint32_t total_claims = total_items * n_seg;
   constexpr uint32_t roulette_threshold = 5;
   const bool material_mode = (A.integrator == VIMG_INTEGRATOR_MATERIAL);
   const uint32_t P = A.pool_slots;
@@ -143,6 +162,10 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
   }
   qv_count0 = P;
   bool pixels_left = true;   // wave-uniform: the global counter still had work last time
+  // wave-uniform: the last finisher batch held nothing but slots that wait for another slot's
+  // segment; the finisher queue is then passed over until some other stage has run, so that a
+  // wave that carries both the waiting slot and the slot it waits for keeps moving
+  bool skip_fin = false;
 
   // ---- persistent walk registers of the lane
   uint32_t w_slot = SLOT_IDLE, w_phase = 0, w_flags = 0, w_cls = 0;
@@ -163,21 +186,27 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
     // vertex batches are sorted by the material class of the hit (known from the primitive at the
     // end of the walk), so that a batch executes one material's code: a full batch of any class
     // runs at once; when the walkers have nothing left, the fullest class runs partially filled
-    const uint32_t qv_max01 = qv_count0 > qv_count1 ? qv_count0 : qv_count1;
+    const uint32_t qv_elig0 = skip_fin ? 0u : qv_count0;
+    const uint32_t qv_max01 = qv_elig0 > qv_count1 ? qv_elig0 : qv_count1;
     const uint32_t qv_max23 = qv_count2 > qv_count3 ? qv_count2 : qv_count3;
     const uint32_t qv_max = qv_max01 > qv_max23 ? qv_max01 : qv_max23;
     // a vertex batch runs when one is full, or when the walkers starve: no queued ray and
     // pool_starve or more idle lanes (the walk would go on half empty while slots wait here)
     const bool run_vertex = (qv_max >= A.pool_vbatch) ||
                             (qv_max > 0u && qw_count == 0u && 64u - n_walking >= A.pool_starve);
-    if (!run_vertex && qw_count == 0u && !inflight) break;   // every queue is empty: all done
+    if (!run_vertex && qw_count == 0u && !inflight) {
+      if (!skip_fin || qv_count0 == 0u) break;   // every queue is empty: all done
+      skip_fin = false;                          // only waiting slots are left: look at them again
+      __builtin_amdgcn_s_sleep(8);
+      continue;
+    }
     if (full_stats && lane == 0) iter_wave++;
 
     if (run_vertex) {
       // ================================================================== VERTEX stage
       PROF_LAP(PF_W_RETIRE)
       [[maybe_unused]] const unsigned long long prof_v0 = PROF_NOW();
-      const uint32_t cls = (qv_count0 == qv_max) ? 0u : (qv_count1 == qv_max ? 1u : (qv_count2 == qv_max ? 2u : 3u));
+      const uint32_t cls = (qv_elig0 == qv_max) ? 0u : (qv_count1 == qv_max ? 1u : (qv_count2 == qv_max ? 2u : 3u));
       const uint32_t qv_count = cls == 0 ? qv_count0 : (cls == 1 ? qv_count1 : (cls == 2 ? qv_count2 : qv_count3));
       const uint32_t qv_head = cls == 0 ? qv_head0 : (cls == 1 ? qv_head1 : (cls == 2 ? qv_head2 : qv_head3));
       const bool finisher_batch = (cls == 0);
@@ -476,11 +505,16 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
       // ---- finished samples: accumulate, pixel write-back, next pixel, next camera ray
       bool need_pixel = fresh;
       bool retire = false;
+      // a fresh slot may already hold a claim whose predecessor segment was not published yet
+      bool have_claim = fresh && (flags & SF_PRIMARY);
+      uint32_t claim = have_claim ? word(SR_RNG, 3, slot) : 0u;
+      bool pending = false;
       if (!finisher_batch) {
         // a path that ended at this vertex (roulette, depth limit, no ray left) is accumulated by
         // the finisher stage: it travels there with neither ray set, which that stage reads as
         // "return bounce_result" (the !SF_HAS_R branch above)
         if (finish) has_s = false, has_r = false;
+        skip_fin = false;
       } else {
       if (finish) {
         if (is_nan(result.x) || is_nan(result.y) || is_nan(result.z)) nan_samples++;
@@ -499,30 +533,52 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
           out[o + 1] = px_col.y;
           out[o + 2] = px_col.z;
           need_pixel = true;
+        } else if (n_seg > 1u && smp % seg_len == 0u) {
+          // end of a segment: the pixel rests in its record until a slot draws its next segment
+          // Every word of the record is read and written with agent-scope atomics (sc1: coherent
+          // across the eight XCDs' L2s on their own), so publishing needs no L2 write-back and
+          // picking up no L2 invalidate - with release / acquire fences at agent scope the cold
+          // slot records would be flushed out of the L2 on every segment end.  Order: data words,
+          // wait until they are acknowledged, then the tag.
+          VIMG_GLOBAL uint32_t* st = reinterpret_cast<VIMG_GLOBAL uint32_t*>(A.pool_state + size_t(item) * 2u);
+          state_store(st + 0, static_cast<uint32_t>(rng.s));
+          state_store(st + 1, static_cast<uint32_t>(rng.s >> 32));
+          state_store(st + 4, fu(acc.x));
+          state_store(st + 5, fu(acc.y));
+          state_store(st + 6, fu(acc.z));
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          state_store(st + 2, A.pool_epoch + smp / seg_len);
+          need_pixel = true;
         }
       }
-      // pixel fetch: repeated while some lane drew an off-image slot of a ragged tile
-      while (__any(need_pixel)) {
-        const unsigned long long mask = __ballot(need_pixel);
+      // work fetch: repeated while some lane drew an off-image slot of a ragged tile
+      while (__any(need_pixel && !pending)) {
+        const bool want = need_pixel && !pending && !have_claim;
+        const unsigned long long mask = __ballot(want);
         uint32_t base = 0;
-        if (pixels_left) {
+        if (mask != 0ull && pixels_left) {
           const uint32_t cntp = __popcll(mask);
           const uint32_t leader = __ffsll(static_cast<long long>(mask)) - 1;
           if (lane == leader) base = atomicAdd(work_counter, cntp);
           base = __shfl(base, leader);
-          if (base >= total_items) {
+          if (base >= total_claims) {
             pixels_left = false;
 #ifdef VIMG_PROFILE
             prof_acc[PF_DRAIN] = __builtin_readcyclecounter();   // time stamp: turned into a span at exit
 #endif
           }
         }
-        if (need_pixel) {
-          item = pixels_left ? base + lane_rank(mask, lane) : total_items;
-          if (item >= total_items) {
+        if (want) {
+          claim = pixels_left ? base + lane_rank(mask, lane) : total_claims;
+          have_claim = true;
+        }
+        if (need_pixel && !pending) {
+          if (claim >= total_claims) {
             retire = true;
             need_pixel = false;
           } else {
+            const uint32_t seg = claim / total_items;
+            item = claim - seg * total_items;
             bool valid = true;
             if (single) {
               px = static_cast<uint32_t>(A.single_x), py = static_cast<uint32_t>(A.single_y);
@@ -534,17 +590,34 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
               py = ty * 8 + (within >> 3);
               valid = (tx < A.tiles_x) && (px < W) && (py < H);
             }
-            if (valid) {
+            if (!valid) {
+              have_claim = false;   // off the image in every segment: draw another item
+            } else if (seg == 0u) {
               const uint64_t image_index = uint64_t(px) + uint64_t(H - 1 - py) * W;
               pcg_seed(rng, image_index);
               smp = 0;
               acc = f3{0.f, 0.f, 0.f};
               need_pixel = false;
+            } else {
+              VIMG_GLOBAL uint32_t* st =
+                  reinterpret_cast<VIMG_GLOBAL uint32_t*>(A.pool_state + size_t(item) * 2u);
+              const uint32_t done = state_load(st + 2);
+              if (done == A.pool_epoch + seg) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const uint32_t r_lo = state_load(st + 0), r_hi = state_load(st + 1);
+                rng.s = uint64_t(r_lo) | (uint64_t(r_hi) << 32);
+                acc = f3{uf(state_load(st + 4)), uf(state_load(st + 5)), uf(state_load(st + 6))};
+                smp = seg * seg_len;
+                need_pixel = false;
+              } else {
+                pending = true;   // the previous segment of this pixel is still in flight somewhere
+              }
             }
           }
         }
       }
-      const bool regen = on && !retire && (finish || fresh);
+      skip_fin = finisher_batch && (__ballot(pending) == __ballot(on));
+      const bool regen = on && !retire && !pending && (finish || fresh);
       if (regen) {
         const f2 off = random_x_y_r2(px + py + smp);
         // right-to-left argument evaluation of the reference's call
@@ -568,9 +641,12 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
       // ---- registers -> slot state, slot -> Q_walk
       const bool keep = on && !retire;
       if (keep) {
-        const uint32_t nf = (primary ? SF_PRIMARY : 0u) | (non_specular_bounce ? SF_NONSPEC : 0u)
-                            | (has_s ? SF_HAS_S : 0u) | (has_r ? SF_HAS_R : 0u)
-                            | (bounce << SF_BOUNCE_SHIFT);
+        // a slot that waits for its item's previous segment stays "fresh" and keeps the claim
+        const uint32_t nf = pending ? (SF_FRESH | SF_PRIMARY)
+                                    : ((primary ? SF_PRIMARY : 0u) | (non_specular_bounce ? SF_NONSPEC : 0u)
+                                       | (has_s ? SF_HAS_S : 0u) | (has_r ? SF_HAS_R : 0u)
+                                       | (bounce << SF_BOUNCE_SHIFT));
+        if (pending) has_s = false, has_r = false, smp = claim;
         wr(SR_ORIGIN, slot, v4u{fu(ray_o.x), fu(ray_o.y), fu(ray_o.z), fu(shadow_max_t)});
         wr(SR_RAY, slot, v4u{fu(ray_d.x), fu(ray_d.y), fu(ray_d.z), nf});
         wr(SR_SHADOW, slot, v4u{fu(shadow_d.x), fu(shadow_d.y), fu(shadow_d.z), 0u});
@@ -594,6 +670,7 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
       PROF_ADD(PF_CLS_CYC0 + cls, PROF_NOW() - prof_v0) PROF_ADD(PF_CLS_LANES0 + cls, n)
     } else {
       // ================================================================== WALK stage
+      skip_fin = false;
       PROF_LAP(PF_W_RETIRE)
       for (;;) {
         PROF_ADD(PF_W_ROUNDS, 1)

@@ -61,6 +61,9 @@ struct VimgDeviceScene {
   float* d_frame = nullptr;
   void* d_pool_cold = nullptr;   // pooled kernel: cold slot records of every resident wave
   size_t pool_cold_bytes = 0;
+  void* d_pool_state = nullptr;  // pooled kernel: per-pixel record between sample segments
+  size_t pool_state_bytes = 0;
+  uint32_t pool_epoch = 0;       // bumped per launch: tags of earlier launches never match
   size_t frame_floats = 0;
 };
 
@@ -301,6 +304,22 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   const uint64_t need_blocks = (items + 255) / 256;
   c.grid = static_cast<uint32_t>(
       std::max<uint64_t>(1, std::min<uint64_t>(need_blocks, uint64_t(s->num_cus) * per_cu)));
+  // pooled kernel: split every pixel's samples into segments handed out as separate work items
+  // when the image is large against the slots in flight (then the previous segment of a pixel
+  // has long been published when its next one is drawn); small images keep one segment
+  a.pool_segments = 1;
+  a.pool_seg_len = p->samples;
+  if (a.pool_slots && sx < 0) {
+    const uint64_t in_flight = uint64_t(c.grid) * 4u * a.pool_slots;
+    // 16 segments of at least 8 samples (config 2: 1 segment 6.8, 4: 7.5, 8: 7.6, 16-32: 7.6 Grays/s)
+    uint32_t k = (items * 2u >= in_flight * 3u) ? std::min<uint32_t>(16u, std::max<uint32_t>(p->samples / 8u, 1u)) : 1u;
+    if (const char* e = getenv("VIMG_HIP_POOL_SEGMENTS")) k = uint32_t(std::max(1, atoi(e)));
+    k = std::min<uint32_t>(k, 4096u);
+    while (k > 1u && items * k >= 0xfff00000ull) --k;   // (segment, pixel) items must fit the 32-bit counter
+    const uint32_t len = std::max<uint32_t>((p->samples + k - 1) / k, 1u);
+    a.pool_seg_len = len;
+    a.pool_segments = std::max<uint32_t>((p->samples + len - 1) / len, 1u);
+  }
   return c;
 }
 
@@ -319,6 +338,28 @@ int ensure_pool(VimgDeviceScene* s, LaunchCfg& c) {
     s->pool_cold_bytes = need;
   }
   c.args.pool_cold = (VIMG_GLOBAL v4u*)s->d_pool_cold;
+  c.args.pool_state = nullptr;
+  c.args.pool_epoch = 0;
+  if (c.args.pool_segments > 1) {
+    const size_t want = size_t(c.args.num_local_tiles) * 64u * 32u;
+    if (want > s->pool_state_bytes) {
+      if (s->d_pool_state) HIP_TRY(hipFree(s->d_pool_state));
+      s->d_pool_state = nullptr;
+      s->pool_state_bytes = 0;
+      HIP_TRY(hipMalloc(&s->d_pool_state, want));
+      HIP_TRY(hipMemset(s->d_pool_state, 0, want));
+      s->pool_state_bytes = want;
+      s->pool_epoch = 0;
+    }
+    // tags are epoch + segment index (< 4096): one epoch step per launch, wrap with a wipe
+    s->pool_epoch += 4096u;
+    if (s->pool_epoch >= 0xffff0000u) {
+      HIP_TRY(hipMemset(s->d_pool_state, 0, s->pool_state_bytes));
+      s->pool_epoch = 4096u;
+    }
+    c.args.pool_state = (VIMG_GLOBAL v4u*)s->d_pool_state;
+    c.args.pool_epoch = s->pool_epoch;
+  }
   return VIMG_OK;
 }
 
@@ -636,6 +677,7 @@ int vimg_hip_scene_free(VimgDeviceScene* s) {
   if (s->d_counter) (void)hipFree(s->d_counter);
   if (s->d_frame) (void)hipFree(s->d_frame);
   if (s->d_pool_cold) (void)hipFree(s->d_pool_cold);
+  if (s->d_pool_state) (void)hipFree(s->d_pool_state);
   delete s;
   return VIMG_OK;
 }
