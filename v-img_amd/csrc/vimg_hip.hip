@@ -53,6 +53,7 @@ struct VimgDeviceScene {
   bool textured = false;       // needs the TEX=true kernels (cones, image textures, env map)
   int waves_per_simd = 2;      // which register-budget build of the kernel to launch
   bool pooled = false;         // render_pool_kernel (LDS path pool) instead of render_kernel
+  bool pool_forced = false;    // ... asked for by name (VIMG_HIP_POOL=1): also for frames too small to fill the pools
   uint32_t num_cus = 0;
   uint32_t num_leaf_prims = 0;   // records in d.leaf_prims (= primitives of the scene)
   // scratch owned by the scene: stats, work counter, host-render framebuffer
@@ -232,11 +233,12 @@ int check_params(const VimgDeviceScene* s, const VimgRenderParams* p) {
 struct LaunchCfg {
   RenderArgs args;
   uint32_t grid, lds_bytes;
+  bool pooled;   // render_pool_kernel for this launch
 };
 
 using RenderKernel = void (*)(const DScene, const RenderArgs, float*, DeviceStats*, unsigned int*);
-RenderKernel pick_kernel(const VimgDeviceScene* s) {
-  if (s->pooled) {
+RenderKernel pick_kernel(const VimgDeviceScene* s, bool pooled) {
+  if (pooled) {
     if (s->textured)
       return s->waves_per_simd >= 3 ? render_pool_kernel<true, 3> : render_pool_kernel<true, 2>;
     return s->waves_per_simd >= 3 ? render_pool_kernel<false, 3> : render_pool_kernel<false, 2>;
@@ -246,8 +248,9 @@ RenderKernel pick_kernel(const VimgDeviceScene* s) {
 }
 
 LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int sx, int sy,
-                      bool for_render = true) {
+                      bool for_render = true, bool allow_pool = true) {
   LaunchCfg c{};
+  c.pooled = s->pooled && for_render && allow_pool;
   RenderArgs& a = c.args;
   a.integrator = p->integrator;
   a.samples = p->samples;
@@ -277,7 +280,7 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   if (const char* e = getenv("VIMG_HIP_POOL_STARVE")) a.pool_starve = uint32_t(std::min(64, std::max(1, atoi(e))));
   if (const char* e = getenv("VIMG_HIP_POOL_VBATCH")) a.pool_vbatch = uint32_t(std::min(64, std::max(1, atoi(e))));
   if (const char* e = getenv("VIMG_HIP_POOL_CLASSES")) a.pool_classes = uint32_t(std::min(3, std::max(1, atoi(e))));
-  if (s->pooled && for_render) {
+  if (c.pooled) {
     // the pool takes what is left of this workgroup's share of the CU's 160 KiB
     const uint32_t share = (160u * 1024u) / uint32_t(s->waves_per_simd) - 1024u;
     const uint32_t per_slot = POOL_LDS_WORDS * 4u * 4u;   // LDS bytes per slot, all four waves
@@ -298,7 +301,7 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   // persistent grid: as many 4-wave workgroups as the kernel's registers and LDS let a CU hold
   // (asked of the runtime), never more than the work
   int per_cu = 0;
-  hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_kernel(s), 256, c.lds_bytes);
+  hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_kernel(s, c.pooled), 256, c.lds_bytes);
   if (oe != hipSuccess || per_cu < 1) per_cu = 1;
   const uint64_t items = (sx >= 0) ? 1 : uint64_t(a.num_local_tiles) * 64u;
   const uint64_t need_blocks = (items + 255) / 256;
@@ -311,8 +314,18 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   a.pool_seg_len = p->samples;
   if (a.pool_slots && sx < 0) {
     const uint64_t in_flight = uint64_t(c.grid) * 4u * a.pool_slots;
-    // 16 segments of at least 8 samples (config 2: 1 segment 6.8, 4: 7.5, 8: 7.6, 16-32: 7.6 Grays/s)
-    uint32_t k = (items * 2u >= in_flight * 3u) ? std::min<uint32_t>(16u, std::max<uint32_t>(p->samples / 8u, 1u)) : 1u;
+    // A frame with fewer pixels than 1.5 x the slots in flight does not fill the pools (904x400:
+    // pooled 3.1, lane-bound 4.5 Grays/s): such launches - small images, thin shards of a strong-
+    // scaling run - go to the lane-bound kernel, unless the pooled one was asked for by name.
+    if (!s->pool_forced && items * 2u < in_flight * 3u) return make_launch(s, p, sx, sy, for_render, false);
+    // Segments: the tail of a frame is one segment long, and every hand-over costs a little
+    // (config 2, 3.5 pool generations per frame: 1 segment 6.8, 4: 7.5, 8: 7.6, 16-32: 7.6 Grays/s;
+    // 3600x1600, 14 generations: 1 segment 7.9, 4: 7.7) - about 56 segments per generation count,
+    // at most 16, of at least 8 samples; frames of 10 generations and more keep their pixels whole
+    const double gens = double(items) / double(in_flight);
+    uint32_t k = gens >= 10.0 ? 1u : uint32_t(std::min(16.0, std::max(1.0, std::floor(56.0 / gens + 0.5))));
+    k = std::min<uint32_t>(k, std::max<uint32_t>(p->samples / 8u, 1u));
+    if (items * 2u < in_flight * 3u) k = 1u;
     if (const char* e = getenv("VIMG_HIP_POOL_SEGMENTS")) k = uint32_t(std::max(1, atoi(e)));
     k = std::min<uint32_t>(k, 4096u);
     while (k > 1u && items * k >= 0xfff00000ull) --k;   // (segment, pixel) items must fit the 32-bit counter
@@ -327,7 +340,7 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
 // resident wave, owned by the scene and grown on demand (42 MB for config 2 on 256 CUs).
 int ensure_pool(VimgDeviceScene* s, LaunchCfg& c) {
   c.args.pool_cold = nullptr;
-  if (!s->pooled || c.args.pool_slots == 0) return VIMG_OK;
+  if (!c.pooled || c.args.pool_slots == 0) return VIMG_OK;
   const size_t ncold = s->textured ? SC_COUNT : SC_COUNT - 1u;
   const size_t need = size_t(c.grid) * 4u * ncold * c.args.pool_slots * 16u;
   if (need > s->pool_cold_bytes) {
@@ -373,9 +386,9 @@ int launch_render(VimgDeviceScene* s, const VimgRenderParams* p, float* d_out, h
   if (want_stats) HIP_TRY(hipMemsetAsync(s->d_stats, 0, sizeof(DeviceStats), st));
   DeviceStats* stats = want_stats ? s->d_stats : nullptr;
   if (c.lds_bytes > 48u * 1024u)   // very deep trees: ask for the large dynamic-LDS carve-out
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(s)),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(s, c.pooled)),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(c.lds_bytes)));
-  hipLaunchKernelGGL(pick_kernel(s), dim3(c.grid), dim3(256), c.lds_bytes, st, s->d, c.args, d_out,
+  hipLaunchKernelGGL(pick_kernel(s, c.pooled), dim3(c.grid), dim3(256), c.lds_bytes, st, s->d, c.args, d_out,
                      stats, s->d_counter);
   HIP_TRY(hipGetLastError());
   return VIMG_OK;
@@ -658,7 +671,10 @@ int vimg_hip_scene_upload(const VimgScene* sc, VimgDeviceScene** out) {
   // pool costs occupancy, which is what the large, latency-bound scenes need (config 4/5: 2x
   // slower), and the textured build's bigger slot state loses the gain (config 3: -6 %)
   s->pooled = !s->textured && s->total_bytes <= (32u << 20);
-  if (const char* e = getenv("VIMG_HIP_POOL")) s->pooled = atoi(e) != 0;
+  if (const char* e = getenv("VIMG_HIP_POOL")) {
+    s->pooled = atoi(e) != 0;
+    s->pool_forced = s->pooled;
+  }
   if (cam.res_x > 65535 || cam.res_y > 65535) s->pooled = false;   // slots pack pixel coordinates
   hipDeviceProp_t prop{};
   if (hipGetDeviceProperties(&prop, g_device) != hipSuccess) return bail(fail(VIMG_E_DEVICE, "hipGetDeviceProperties failed"));
@@ -688,7 +704,10 @@ const char* vimg_hip_scene_kernel(const VimgDeviceScene* s) {
       {{"render_kernel<false,2>", "render_kernel<false,3>"}, {"render_kernel<true,2>", "render_kernel<true,3>"}},
       {{"render_pool_kernel<false,2>", "render_pool_kernel<false,3>"},
        {"render_pool_kernel<true,2>", "render_pool_kernel<true,3>"}}};
-  return names[s->pooled ? 1 : 0][s->textured ? 1 : 0][s->waves_per_simd >= 3 ? 1 : 0];
+  // the choice between the two schedulers is made per launch: report the one of a whole frame
+  const VimgRenderParams whole{VIMG_INTEGRATOR_MIS, 64, 1, 0, 1};
+  const LaunchCfg c = make_launch(s, &whole, -1, -1);
+  return names[c.pooled ? 1 : 0][s->textured ? 1 : 0][s->waves_per_simd >= 3 ? 1 : 0];
 }
 
 int64_t vimg_hip_scene_bytes(const VimgDeviceScene* s) {
@@ -811,10 +830,10 @@ int vimg_hip_time_renders(VimgDeviceScene* s, const VimgRenderParams* p, void* d
     LaunchCfg c = make_launch(s, p, -1, -1);
     if (int rc = ensure_pool(s, c)) return rc;
     if (c.lds_bytes > 48u * 1024u)
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(s)),
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(s, c.pooled)),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(c.lds_bytes)));
     HIP_TRY(hipEventRecord(ev[2 * i], g_stream));
-    hipLaunchKernelGGL(pick_kernel(s), dim3(c.grid), dim3(256), c.lds_bytes, g_stream, s->d, c.args,
+    hipLaunchKernelGGL(pick_kernel(s, c.pooled), dim3(c.grid), dim3(256), c.lds_bytes, g_stream, s->d, c.args,
                        static_cast<float*>(d_out), static_cast<DeviceStats*>(nullptr), s->d_counter);
     HIP_TRY(hipEventRecord(ev[2 * i + 1], g_stream));
   }
