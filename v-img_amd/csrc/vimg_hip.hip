@@ -53,6 +53,7 @@ struct VimgDeviceScene {
   bool textured = false;       // needs the TEX=true kernels (cones, image textures, env map)
   int waves_per_simd = 2;      // which register-budget build of the kernel to launch
   bool pooled = false;         // render_pool_kernel (LDS path pool) instead of render_kernel
+  bool wps_forced = false;     // register budget asked for by name (VIMG_HIP_WAVES_PER_SIMD)
   bool pool_forced = false;    // ... asked for by name (VIMG_HIP_POOL=1): also for frames too small to fill the pools
   uint32_t num_cus = 0;
   uint32_t num_leaf_prims = 0;   // records in d.leaf_prims (= primitives of the scene)
@@ -234,23 +235,29 @@ struct LaunchCfg {
   RenderArgs args;
   uint32_t grid, lds_bytes;
   bool pooled;   // render_pool_kernel for this launch
+  int wps;       // register-budget build (waves per SIMD of __launch_bounds__)
 };
 
 using RenderKernel = void (*)(const DScene, const RenderArgs, float*, DeviceStats*, unsigned int*);
-RenderKernel pick_kernel(const VimgDeviceScene* s, bool pooled) {
+RenderKernel pick_kernel(const VimgDeviceScene* s, bool pooled, int wps) {
   if (pooled) {
-    if (s->textured)
-      return s->waves_per_simd >= 3 ? render_pool_kernel<true, 3> : render_pool_kernel<true, 2>;
-    return s->waves_per_simd >= 3 ? render_pool_kernel<false, 3> : render_pool_kernel<false, 2>;
+    if (s->textured) return wps >= 3 ? render_pool_kernel<true, 3> : render_pool_kernel<true, 2>;
+    return wps >= 3 ? render_pool_kernel<false, 3> : render_pool_kernel<false, 2>;
   }
-  if (s->textured) return s->waves_per_simd >= 3 ? render_kernel<true, 3> : render_kernel<true, 2>;
-  return s->waves_per_simd >= 3 ? render_kernel<false, 3> : render_kernel<false, 2>;
+  if (s->textured) return wps >= 3 ? render_kernel<true, 3> : render_kernel<true, 2>;
+  return wps >= 3 ? render_kernel<false, 3> : render_kernel<false, 2>;
 }
 
 LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int sx, int sy,
                       bool for_render = true, bool allow_pool = true) {
   LaunchCfg c{};
   c.pooled = s->pooled && for_render && allow_pool;
+  // register budget: the lane-bound kernel wants 3 waves per SIMD on scenes beyond the on-chip
+  // caches (latency-bound) and 2 on small ones (VALU-bound, fewest spills); the pooled kernel
+  // hides latency with its slots and always takes the 256-register build (config 4/5: 2 waves
+  // 1.02 / 1.70 Grays/s, 3 waves 0.66 / 0.91)
+  c.wps = c.pooled ? 2 : s->waves_per_simd;
+  if (s->wps_forced) c.wps = s->waves_per_simd;
   RenderArgs& a = c.args;
   a.integrator = p->integrator;
   a.samples = p->samples;
@@ -267,7 +274,10 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   // LDS budget per 256-thread workgroup: stacks first, then as much of the top of the tree as
   // fits in 40 KiB total (keeps >= 4 workgroups per CU inside the 160 KiB)
   const uint32_t stack_bytes = 4u * a.stack_entries * 64u * 4u;
-  const uint32_t budget = 40u * 1024u;
+  // (the pooled kernel spends LDS on path slots instead: it keeps the first six levels of the tree,
+  // 4 KiB - config 5: 40 KiB budget 1.69, 28 KiB 1.78 Grays/s)
+  uint32_t budget = c.pooled ? std::min(40u * 1024u, stack_bytes + 4608u) : 40u * 1024u;
+  if (const char* e = getenv("VIMG_HIP_LDS_BUDGET_KB")) budget = uint32_t(std::max(1, atoi(e))) * 1024u;
   uint32_t nodes = 0;
   if (stack_bytes + 512 < budget) nodes = (budget - stack_bytes - 256) / 56u;
   a.lds_nodes = std::min(nodes, s->d.num_nodes);
@@ -282,7 +292,7 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   if (const char* e = getenv("VIMG_HIP_POOL_CLASSES")) a.pool_classes = uint32_t(std::min(3, std::max(1, atoi(e))));
   if (c.pooled) {
     // the pool takes what is left of this workgroup's share of the CU's 160 KiB
-    const uint32_t share = (160u * 1024u) / uint32_t(s->waves_per_simd) - 1024u;
+    const uint32_t share = (160u * 1024u) / uint32_t(c.wps) - 1024u;
     const uint32_t per_slot = POOL_LDS_WORDS * 4u * 4u;   // LDS bytes per slot, all four waves
     // small scenes: all leaf records in LDS too (they cost a few slots, the walk gains more)
     uint32_t leaf_bytes = 0;
@@ -301,7 +311,7 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   // persistent grid: as many 4-wave workgroups as the kernel's registers and LDS let a CU hold
   // (asked of the runtime), never more than the work
   int per_cu = 0;
-  hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_kernel(s, c.pooled), 256, c.lds_bytes);
+  hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_kernel(s, c.pooled, c.wps), 256, c.lds_bytes);
   if (oe != hipSuccess || per_cu < 1) per_cu = 1;
   const uint64_t items = (sx >= 0) ? 1 : uint64_t(a.num_local_tiles) * 64u;
   const uint64_t need_blocks = (items + 255) / 256;
@@ -386,9 +396,9 @@ int launch_render(VimgDeviceScene* s, const VimgRenderParams* p, float* d_out, h
   if (want_stats) HIP_TRY(hipMemsetAsync(s->d_stats, 0, sizeof(DeviceStats), st));
   DeviceStats* stats = want_stats ? s->d_stats : nullptr;
   if (c.lds_bytes > 48u * 1024u)   // very deep trees: ask for the large dynamic-LDS carve-out
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(s, c.pooled)),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(s, c.pooled, c.wps)),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(c.lds_bytes)));
-  hipLaunchKernelGGL(pick_kernel(s, c.pooled), dim3(c.grid), dim3(256), c.lds_bytes, st, s->d, c.args, d_out,
+  hipLaunchKernelGGL(pick_kernel(s, c.pooled, c.wps), dim3(c.grid), dim3(256), c.lds_bytes, st, s->d, c.args, d_out,
                      stats, s->d_counter);
   HIP_TRY(hipGetLastError());
   return VIMG_OK;
@@ -665,12 +675,15 @@ int vimg_hip_scene_upload(const VimgScene* sc, VimgDeviceScene** out) {
   // kernel build: scenes beyond the on-chip caches are latency-bound and want more waves per
   // SIMD; small scenes are VALU-bound and want the build that spills least
   s->waves_per_simd = (s->total_bytes > (32u << 20)) ? 3 : 2;
-  if (const char* e = getenv("VIMG_HIP_WAVES_PER_SIMD")) s->waves_per_simd = atoi(e);
-  // which kernel: the pooled variant (paths decoupled from lanes through an LDS pool) wins where
-  // the scene is on chip and the walk is short, i.e. VALU-bound work (config 2: +8.5 %); its LDS
-  // pool costs occupancy, which is what the large, latency-bound scenes need (config 4/5: 2x
-  // slower), and the textured build's bigger slot state loses the gain (config 3: -6 %)
-  s->pooled = !s->textured && s->total_bytes <= (32u << 20);
+  if (const char* e = getenv("VIMG_HIP_WAVES_PER_SIMD")) {
+    s->waves_per_simd = atoi(e);
+    s->wps_forced = true;
+  }
+  // which scheduler: the pooled one (paths decoupled from lanes, render_pool_kernel.h) wherever a
+  // frame can fill its pools - measured on all five configurations (config 2 +36 %, 3 +36 %,
+  // 4 +24 %, 5 +14 % over the lane-bound kernel); make_launch falls back to the lane-bound kernel
+  // per launch for frames and shards too small for that
+  s->pooled = true;
   if (const char* e = getenv("VIMG_HIP_POOL")) {
     s->pooled = atoi(e) != 0;
     s->pool_forced = s->pooled;
@@ -707,7 +720,7 @@ const char* vimg_hip_scene_kernel(const VimgDeviceScene* s) {
   // the choice between the two schedulers is made per launch: report the one of a whole frame
   const VimgRenderParams whole{VIMG_INTEGRATOR_MIS, 64, 1, 0, 1};
   const LaunchCfg c = make_launch(s, &whole, -1, -1);
-  return names[c.pooled ? 1 : 0][s->textured ? 1 : 0][s->waves_per_simd >= 3 ? 1 : 0];
+  return names[c.pooled ? 1 : 0][s->textured ? 1 : 0][c.wps >= 3 ? 1 : 0];
 }
 
 int64_t vimg_hip_scene_bytes(const VimgDeviceScene* s) {
@@ -830,10 +843,10 @@ int vimg_hip_time_renders(VimgDeviceScene* s, const VimgRenderParams* p, void* d
     LaunchCfg c = make_launch(s, p, -1, -1);
     if (int rc = ensure_pool(s, c)) return rc;
     if (c.lds_bytes > 48u * 1024u)
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(s, c.pooled)),
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(s, c.pooled, c.wps)),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(c.lds_bytes)));
     HIP_TRY(hipEventRecord(ev[2 * i], g_stream));
-    hipLaunchKernelGGL(pick_kernel(s, c.pooled), dim3(c.grid), dim3(256), c.lds_bytes, g_stream, s->d, c.args,
+    hipLaunchKernelGGL(pick_kernel(s, c.pooled, c.wps), dim3(c.grid), dim3(256), c.lds_bytes, g_stream, s->d, c.args,
                        static_cast<float*>(d_out), static_cast<DeviceStats*>(nullptr), s->d_counter);
     HIP_TRY(hipEventRecord(ev[2 * i + 1], g_stream));
   }
