@@ -259,6 +259,44 @@ def test_full_size_properties_disney_spheres():
     assert np.allclose(d.trace_pixel(p, 900, 400), ref, rtol=1e-5, atol=1e-6)
 
 
+def test_full_size_schedulers_and_segments_agree(monkeypatch):
+    """BASELINE config 2 at full resolution: the upload policy launches the pooled kernel with the
+    samples of a pixel cut into segments (items = 3.5 pool generations), a thin shard of the same
+    frame goes to the lane-bound kernel; both give the bits of the lane-bound kernel on the whole
+    frame.  Size-independent property: the image does not depend on scheduler, segment count or
+    shard count."""
+    s = scenes.json_scene("disney_spheres.json")
+    p = s.default_params(samples=16)
+    d = _dev(s)
+    assert d.kernel.startswith("render_pool_kernel")
+    auto, st_auto = d.render_to_host(p)
+    monkeypatch.setenv("VIMG_HIP_POOL_SEGMENTS", "7")      # 16 samples in segments of 3 (+1)
+    seg, st_seg = _dev(s).render_to_host(p)
+    monkeypatch.delenv("VIMG_HIP_POOL_SEGMENTS")
+    monkeypatch.setenv("VIMG_HIP_POOL", "0")
+    lane_dev = _dev(s)
+    assert lane_dev.kernel.startswith("render_kernel")
+    lane, st_lane = lane_dev.render_to_host(p)
+    assert np.array_equal(auto.view(np.uint32), lane.view(np.uint32))
+    assert np.array_equal(seg.view(np.uint32), lane.view(np.uint32))
+    assert st_auto.as_dict() == st_lane.as_dict() == st_seg.as_dict()
+    monkeypatch.delenv("VIMG_HIP_POOL")
+    # an eighth of the frame (what one GPU of eight renders under --strong): too small for the pools
+    import torch
+    from vimg_amd import dist as vdist
+    p8 = s.default_params(samples=16, tile_rank=3, tile_world=8)
+    slab, _ = d.render(p8)
+    stride = vdist.shard_stride_pixels(1800, 800, 8)
+    gathered = np.zeros((8, stride, 3), dtype=np.float32)
+    gathered[3, :slab.shape[0]] = slab.cpu().numpy()
+    mine = vdist.assemble_numpy(gathered, 1800, 800, 8)
+    mask = np.zeros((8, stride, 3), dtype=np.float32)
+    mask[3, :slab.shape[0]] = 1
+    own = vdist.assemble_numpy(mask, 1800, 800, 8)[..., 0] > 0
+    assert own.sum() == slab.shape[0]
+    assert np.array_equal(mine[own].view(np.uint32), lane[own].view(np.uint32))
+
+
 def test_error_paths():
     from vimg_amd import hip
     s = scenes.json_scene("disney_spheres.json", res=(32, 16))
