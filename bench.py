@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=512)
     ap.add_argument("--strong", action="store_true", help="keep 1800x800 total (strong scaling)")
-    ap.add_argument("--cpu-spp", type=int, default=16, help="samples of the CPU baseline leg")
+    ap.add_argument("--cpu-spp", type=int, default=64, help="samples of the CPU baseline leg (about 15 s on 16 threads)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path (host-staged gather), not a measurement")

@@ -166,6 +166,7 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
   // segment; the finisher queue is then passed over until some other stage has run, so that a
   // wave that carries both the waiting slot and the slot it waits for keeps moving
   bool skip_fin = false;
+  uint32_t idle_polls = 0;   // consecutive main-loop turns that found only waiting slots
 
   // ---- persistent walk registers of the lane
   uint32_t w_slot = SLOT_IDLE, w_phase = 0, w_flags = 0, w_cls = 0;
@@ -197,6 +198,14 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
     if (!run_vertex && qw_count == 0u && !inflight) {
       if (!skip_fin || qv_count0 == 0u) break;   // every queue is empty: all done
       skip_fin = false;                          // only waiting slots are left: look at them again
+      // Watchdog: the wait is for segments other waves are working on, i.e. for at most the time
+      // of a few samples.  A wave that has looked a million times in a row (seconds) is stuck on
+      // something that will not come; it raises the error word behind the work counter and
+      // leaves, so that a scheduling bug ends as VIMG_E_DEVICE instead of a hung GPU.
+      if (++idle_polls > (1u << 20)) {
+        if (lane == 0) atomicOr(work_counter + 1, 1u);
+        break;
+      }
       __builtin_amdgcn_s_sleep(8);
       continue;
     }
@@ -515,6 +524,7 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
         // "return bounce_result" (the !SF_HAS_R branch above)
         if (finish) has_s = false, has_r = false;
         skip_fin = false;
+        idle_polls = 0;
       } else {
       if (finish) {
         if (is_nan(result.x) || is_nan(result.y) || is_nan(result.z)) nan_samples++;
@@ -617,6 +627,7 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
         }
       }
       skip_fin = finisher_batch && (__ballot(pending) == __ballot(on));
+      if (!skip_fin) idle_polls = 0;
       const bool regen = on && !retire && !pending && (finish || fresh);
       if (regen) {
         const f2 off = random_x_y_r2(px + py + smp);
@@ -671,6 +682,7 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
     } else {
       // ================================================================== WALK stage
       skip_fin = false;
+      idle_polls = 0;
       PROF_LAP(PF_W_RETIRE)
       for (;;) {
         PROF_ADD(PF_W_ROUNDS, 1)

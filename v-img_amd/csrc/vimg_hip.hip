@@ -392,7 +392,7 @@ int launch_render(VimgDeviceScene* s, const VimgRenderParams* p, float* d_out, h
   if (int rc = ensure_pool(s, c)) return rc;
   c.args.full_stats = full_stats ? 1u : 0u;
   if (c.args.num_local_tiles == 0 && sx < 0) return VIMG_OK;
-  HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(unsigned int), st));
+  HIP_TRY(hipMemsetAsync(s->d_counter, 0, 2 * sizeof(unsigned int), st));
   if (want_stats) HIP_TRY(hipMemsetAsync(s->d_stats, 0, sizeof(DeviceStats), st));
   DeviceStats* stats = want_stats ? s->d_stats : nullptr;
   if (c.lds_bytes > 48u * 1024u)   // very deep trees: ask for the large dynamic-LDS carve-out
@@ -401,6 +401,16 @@ int launch_render(VimgDeviceScene* s, const VimgRenderParams* p, float* d_out, h
   hipLaunchKernelGGL(pick_kernel(s, c.pooled, c.wps), dim3(c.grid), dim3(256), c.lds_bytes, st, s->d, c.args, d_out,
                      stats, s->d_counter);
   HIP_TRY(hipGetLastError());
+  return VIMG_OK;
+}
+
+// d_counter[1] is the error word of the last launch (raised by the pooled kernel's watchdog)
+int check_kernel_error(VimgDeviceScene* s) {
+  unsigned int words[2] = {0, 0};
+  HIP_TRY(hipMemcpy(words, s->d_counter, sizeof(words), hipMemcpyDeviceToHost));
+  if (words[1] != 0)
+    return fail(VIMG_E_DEVICE, "render kernel watchdog: a wave waited for work that never came "
+                               "(the frame is incomplete)");
   return VIMG_OK;
 }
 
@@ -693,7 +703,7 @@ int vimg_hip_scene_upload(const VimgScene* sc, VimgDeviceScene** out) {
   if (hipGetDeviceProperties(&prop, g_device) != hipSuccess) return bail(fail(VIMG_E_DEVICE, "hipGetDeviceProperties failed"));
   s->num_cus = static_cast<uint32_t>(prop.multiProcessorCount);
   if (hipMalloc(reinterpret_cast<void**>(&s->d_stats), sizeof(DeviceStats)) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void**>(&s->d_counter), sizeof(unsigned int)) != hipSuccess)
+      hipMalloc(reinterpret_cast<void**>(&s->d_counter), 2 * sizeof(unsigned int)) != hipSuccess)
     return bail(fail(VIMG_E_DEVICE, "hipMalloc of scratch failed"));
   *out = s;
   return VIMG_OK;
@@ -750,6 +760,7 @@ int vimg_hip_render(VimgDeviceScene* s, const VimgRenderParams* p, void* d_out, 
   rc = launch_render(s, p, static_cast<float*>(d_out), st, stats != nullptr, stats != nullptr, -1, -1);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(st));
+  if (int rc2 = check_kernel_error(s)) return rc2;
   if (stats) return fetch_stats(s, p, stats);
   return VIMG_OK;
 }
@@ -839,7 +850,7 @@ int vimg_hip_time_renders(VimgDeviceScene* s, const VimgRenderParams* p, void* d
   for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
   for (int i = 0; i < steps; ++i) {
     // the counter reset is part of a launch's prologue; the events bracket the kernel only
-    HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(unsigned int), g_stream));
+    HIP_TRY(hipMemsetAsync(s->d_counter, 0, 2 * sizeof(unsigned int), g_stream));
     LaunchCfg c = make_launch(s, p, -1, -1);
     if (int rc = ensure_pool(s, c)) return rc;
     if (c.lds_bytes > 48u * 1024u)
@@ -851,6 +862,7 @@ int vimg_hip_time_renders(VimgDeviceScene* s, const VimgRenderParams* p, void* d
     HIP_TRY(hipEventRecord(ev[2 * i + 1], g_stream));
   }
   HIP_TRY(hipStreamSynchronize(g_stream));
+  if (int rc2 = check_kernel_error(s)) return rc2;
   for (int i = 0; i < steps; ++i) HIP_TRY(hipEventElapsedTime(&ms_per_launch[i], ev[2 * i], ev[2 * i + 1]));
   for (auto& e : ev) (void)hipEventDestroy(e);
   return VIMG_OK;
