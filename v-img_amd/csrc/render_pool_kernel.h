@@ -88,7 +88,10 @@ VD uint32_t lane_rank(unsigned long long mask, uint32_t lane) {
   return __popcll(mask & ((1ull << lane) - 1ull));
 }
 
-template <bool TEX, int WPS>
+// DEEP: the tree does not fit the LDS node cache (deep, memory-resident trees): the box loop hands
+// over to the leaf loop as soon as fewer than pool_boxmin lanes still descend.  On trees that sit
+// in LDS the test costs more than it brings (config 2: -3 %), hence a build without it.
+template <bool TEX, int WPS, bool DEEP>
 __global__ void __launch_bounds__(256, WPS)
 render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
                    DeviceStats* __restrict__ stats, unsigned int* __restrict__ work_counter) {
@@ -136,6 +139,7 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
     if (A.lds_leaf) __syncthreads();
   }
   const bool leaf_in_lds = A.lds_leaf != 0u;
+  const uint32_t box_min = A.pool_boxmin;
   VIMG_LDS v4u* recs = reinterpret_cast<VIMG_LDS v4u*>(pool);
   auto rd = [&](uint32_t r, uint32_t slot) -> v4u { return recs[r * P + slot]; };
   auto wr = [&](uint32_t r, uint32_t slot, v4u v) { recs[r * P + slot] = v; };
@@ -779,9 +783,14 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
             } else {
               cur = REF_DONE;
             }
+            // deep trees: when only a few lanes still descend, the lanes that wait at a leaf go
+            // first (the box loop of the config-5 stand-in ran with 27 % of its lanes busy)
+            if constexpr (DEEP) {
+              if (__popcll(__ballot(cur != REF_DONE && ref_count(cur) == 0)) < box_min) break;
+            }
           }
           PROF_LAP(PF_W_BOX)
-          if (cur != REF_DONE) {
+          if (cur != REF_DONE && (!DEEP || ref_count(cur) != 0)) {
             const uint32_t first = ref_index(cur), count = ref_count(cur);
             if (full_stats) cnt.leaf++;
             bool stop = false;

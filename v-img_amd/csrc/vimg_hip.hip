@@ -236,13 +236,18 @@ struct LaunchCfg {
   uint32_t grid, lds_bytes;
   bool pooled;   // render_pool_kernel for this launch
   int wps;       // register-budget build (waves per SIMD of __launch_bounds__)
+  bool deep;     // pooled kernel: build whose box loop yields to waiting leaves (tree beyond the LDS node cache)
 };
 
 using RenderKernel = void (*)(const DScene, const RenderArgs, float*, DeviceStats*, unsigned int*);
-RenderKernel pick_kernel(const VimgDeviceScene* s, bool pooled, int wps) {
+RenderKernel pick_kernel(const VimgDeviceScene* s, bool pooled, int wps, bool deep) {
   if (pooled) {
-    if (s->textured) return wps >= 3 ? render_pool_kernel<true, 3> : render_pool_kernel<true, 2>;
-    return wps >= 3 ? render_pool_kernel<false, 3> : render_pool_kernel<false, 2>;
+    if (deep) {
+      if (s->textured) return wps >= 3 ? render_pool_kernel<true, 3, true> : render_pool_kernel<true, 2, true>;
+      return wps >= 3 ? render_pool_kernel<false, 3, true> : render_pool_kernel<false, 2, true>;
+    }
+    if (s->textured) return wps >= 3 ? render_pool_kernel<true, 3, false> : render_pool_kernel<true, 2, false>;
+    return wps >= 3 ? render_pool_kernel<false, 3, false> : render_pool_kernel<false, 2, false>;
   }
   if (s->textured) return wps >= 3 ? render_kernel<true, 3> : render_kernel<true, 2>;
   return wps >= 3 ? render_kernel<false, 3> : render_kernel<false, 2>;
@@ -287,6 +292,11 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   a.pool_vbatch = 64;
   a.pool_classes = 3;
   a.pool_starve = 24;
+  // config 4 / 5 stand-ins: never 1.02 / 1.74, 8 lanes 1.19 / 2.10, 16: 1.18 / 2.13, 24: 1.20 / 2.13,
+  // 40: 1.15 / 1.93 Grays/s
+  a.pool_boxmin = 16;
+  if (const char* e = getenv("VIMG_HIP_POOL_BOXMIN")) a.pool_boxmin = uint32_t(std::min(64, std::max(0, atoi(e))));
+  c.deep = c.pooled && a.lds_nodes < s->d.num_nodes && a.pool_boxmin != 0;
   if (const char* e = getenv("VIMG_HIP_POOL_STARVE")) a.pool_starve = uint32_t(std::min(64, std::max(1, atoi(e))));
   if (const char* e = getenv("VIMG_HIP_POOL_VBATCH")) a.pool_vbatch = uint32_t(std::min(64, std::max(1, atoi(e))));
   if (const char* e = getenv("VIMG_HIP_POOL_CLASSES")) a.pool_classes = uint32_t(std::min(3, std::max(1, atoi(e))));
@@ -311,7 +321,7 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   // persistent grid: as many 4-wave workgroups as the kernel's registers and LDS let a CU hold
   // (asked of the runtime), never more than the work
   int per_cu = 0;
-  hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_kernel(s, c.pooled, c.wps), 256, c.lds_bytes);
+  hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_kernel(s, c.pooled, c.wps, c.deep), 256, c.lds_bytes);
   if (oe != hipSuccess || per_cu < 1) per_cu = 1;
   const uint64_t items = (sx >= 0) ? 1 : uint64_t(a.num_local_tiles) * 64u;
   const uint64_t need_blocks = (items + 255) / 256;
@@ -396,9 +406,9 @@ int launch_render(VimgDeviceScene* s, const VimgRenderParams* p, float* d_out, h
   if (want_stats) HIP_TRY(hipMemsetAsync(s->d_stats, 0, sizeof(DeviceStats), st));
   DeviceStats* stats = want_stats ? s->d_stats : nullptr;
   if (c.lds_bytes > 48u * 1024u)   // very deep trees: ask for the large dynamic-LDS carve-out
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(s, c.pooled, c.wps)),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(s, c.pooled, c.wps, c.deep)),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(c.lds_bytes)));
-  hipLaunchKernelGGL(pick_kernel(s, c.pooled, c.wps), dim3(c.grid), dim3(256), c.lds_bytes, st, s->d, c.args, d_out,
+  hipLaunchKernelGGL(pick_kernel(s, c.pooled, c.wps, c.deep), dim3(c.grid), dim3(256), c.lds_bytes, st, s->d, c.args, d_out,
                      stats, s->d_counter);
   HIP_TRY(hipGetLastError());
   return VIMG_OK;
@@ -727,9 +737,13 @@ const char* vimg_hip_scene_kernel(const VimgDeviceScene* s) {
       {{"render_kernel<false,2>", "render_kernel<false,3>"}, {"render_kernel<true,2>", "render_kernel<true,3>"}},
       {{"render_pool_kernel<false,2>", "render_pool_kernel<false,3>"},
        {"render_pool_kernel<true,2>", "render_pool_kernel<true,3>"}}};
+  static const char* deep_names[2][2] = {
+      {"render_pool_kernel<false,2,deep>", "render_pool_kernel<false,3,deep>"},
+      {"render_pool_kernel<true,2,deep>", "render_pool_kernel<true,3,deep>"}};
   // the choice between the two schedulers is made per launch: report the one of a whole frame
   const VimgRenderParams whole{VIMG_INTEGRATOR_MIS, 64, 1, 0, 1};
   const LaunchCfg c = make_launch(s, &whole, -1, -1);
+  if (c.deep) return deep_names[s->textured ? 1 : 0][c.wps >= 3 ? 1 : 0];
   return names[c.pooled ? 1 : 0][s->textured ? 1 : 0][c.wps >= 3 ? 1 : 0];
 }
 
@@ -854,10 +868,10 @@ int vimg_hip_time_renders(VimgDeviceScene* s, const VimgRenderParams* p, void* d
     LaunchCfg c = make_launch(s, p, -1, -1);
     if (int rc = ensure_pool(s, c)) return rc;
     if (c.lds_bytes > 48u * 1024u)
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(s, c.pooled, c.wps)),
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(s, c.pooled, c.wps, c.deep)),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(c.lds_bytes)));
     HIP_TRY(hipEventRecord(ev[2 * i], g_stream));
-    hipLaunchKernelGGL(pick_kernel(s, c.pooled, c.wps), dim3(c.grid), dim3(256), c.lds_bytes, g_stream, s->d, c.args,
+    hipLaunchKernelGGL(pick_kernel(s, c.pooled, c.wps, c.deep), dim3(c.grid), dim3(256), c.lds_bytes, g_stream, s->d, c.args,
                        static_cast<float*>(d_out), static_cast<DeviceStats*>(nullptr), s->d_counter);
     HIP_TRY(hipEventRecord(ev[2 * i + 1], g_stream));
   }
