@@ -424,6 +424,13 @@ def test_bsdf_sampling_draws_from_the_pdf_it_reports(name, mat):
         [np.tile(np.concatenate([o, d]), (k, 1)), dirs, np.zeros((k, 3), np.float32)], 1).astype(np.float32))
     pdf_all = ev[:, 4].astype(np.float64)
     assert np.all(np.isfinite(pdf_all)) and pdf_all.min() >= 0
+    # the evaluated f carries the cosine, so its integral is the directional albedo: exactly the
+    # texture colour for Lambertian, and no lobe mix may create energy
+    albedo = ev[:, 1:4].astype(np.float64).sum(axis=0) / k * 4 * np.pi
+    print(f"{name}: directional albedo {np.round(albedo, 4)}")
+    assert np.all(albedo <= 1.02) and np.all(albedo > 0.05)
+    if name == "lambertian":
+        assert np.allclose(albedo, (0.7, 0.6, 0.5), atol=2e-3)
     glass = "glass" in name
     phantom = 0.0
     if glass:
