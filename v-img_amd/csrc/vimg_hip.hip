@@ -991,7 +991,7 @@ int vimg_hip_build_env_cdfs(const float* img, uint32_t w, uint32_t h, float* row
   hipLaunchKernelGGL(pre_env_lum_kernel, dim3(pre_grid(n)), dim3(256), 0, g_stream, d_img.f32(), w, h,
                      d_sin.f32(), d_lum.f32());
   // one conditional distribution per image row, then the marginal over the row integrals
-  hipLaunchKernelGGL(pre_cdf_scan_kernel, dim3((h + 63) / 64), dim3(64), 0, g_stream, d_lum.f32(), h, w,
+  hipLaunchKernelGGL(pre_cdf_scan_kernel, dim3(h), dim3(64), 0, g_stream, d_lum.f32(), h, w,
                      d_cdf.f32(), d_rowint.f32());
   hipLaunchKernelGGL(pre_cdf_normalise_kernel, dim3(pre_grid(size_t(h) * (w + 1))), dim3(256), 0, g_stream,
                      d_cdf.f32(), h, w, d_rowint.f32());
