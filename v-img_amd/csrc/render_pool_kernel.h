@@ -1,37 +1,37 @@
-// Pooled variant of the render kernel: every wave owns a POOL of path slots in LDS (about two per
+// Pooled scheduler of the render path: every wave owns a POOL of about 200 path slots (three per
 // lane) instead of binding one path to one lane.
 //
 // Why: in render_kernel a lane is idle whenever its own path does not need the phase the wave is
 // in (31 % of lanes in the shadow walk, ~30 % in the vertex phase), and a path whose BVH walk is
 // long holds its lane's next vertex back.  Here paths are decoupled from lanes:
-//   * slot state is split by who touches it: the three records the WALK reads and writes (origin,
-//     path ray + flags, shadow ray / hit barycentrics) and the primitive id live in LDS, SoA
-//     [record][slot]; the records only the vertex stage touches late (throughput, result, NEE term,
-//     pixel accumulator, cone) live in a per-wave region of global memory (L2 / Infinity-Cache
-//     resident, read and written with coalesced 16-byte accesses once per batch).  Keeping the cold
-//     80 bytes out of LDS more than doubles the number of slots a wave can hold (~119 -> 246), and
-//     the measured gain per slot is steep (72 slots 4.7, 104 slots 6.0, 119 slots 6.4 Grays/s);
-//   * two wave-private queues hold slot ids: Q_walk (rays ready to be walked) and Q_vertex (walks
-//     finished, or a new path needed).  The queues are used by one wave only, so pushing and
-//     popping is __ballot/popcount arithmetic on wave-uniform counters — no atomics, no waiting;
+//   * slot state is split by who touches it: the records the WALK reads and writes (origin, path
+//     ray + flags, shadow ray / hit barycentrics), the RNG record and the primitive id live in
+//     LDS, SoA [record][slot]; the records the vertex stage touches late (throughput, result, NEE
+//     term, pixel accumulator, cone) live in a per-wave region of global memory, [slot][record]
+//     (L2 / Infinity-Cache resident, read and written once per batch).  Keeping the cold 64 bytes
+//     out of LDS takes a wave from 119 to 201 slots, and the measured gain per slot is steep
+//     (72 slots 4.7, 104 slots 6.0, 119 slots 6.4, 201 slots 6.9 Grays/s on config 2);
+//   * wave-private queues hold slot ids: Q_walk (rays ready to be walked) and four Q_vertex rings
+//     (walks finished, by class).  The queues are used by one wave only, so pushing and popping is
+//     __ballot/popcount arithmetic on wave-uniform counters — no atomics, no waiting;
 //   * the VERTEX stage runs on batches of up to 64 slots of ONE class, known when the walk ends from
 //     the flags and the material class baked into the leaf record: class 0 = "finishers" (miss,
 //     emitter hit, failed BSDF sample, roulette death: NEE result, emitter / miss MIS weight, pixel
-//     accumulation, next camera ray), classes 1-3 = path vertices by material (hit record,
-//     roulette, light sample, BSDF sample, both BSDF evaluations).  A path that ends inside a
-//     vertex batch is handed to the finisher queue, so every stage runs with its lanes full;
-//   * the WALK stage is a persistent while-while loop whose lanes refill from Q_walk the moment
-//     their ray is done (shadow ray first, then the path ray of the same vertex), so the box loop
-//     and the primitive loop keep their lanes busy.
-//   * a pixel is bound to a slot for one SEGMENT of its samples only (an eighth of them): the work
-//     items of the global counter are (segment, pixel) pairs in segment-major order, and between
-//     segments the pixel's state (RNG, accumulator) rests in a per-pixel record in global memory,
-//     published with a release store and picked up with an acquire load by whichever slot draws
-//     the next segment.  A frame then ends with the ragged tail of one segment instead of one
-//     whole pixel (config 2: every wave's last pixels ran 512 samples in a draining pool, a
-//     quarter of the frame at falling efficiency and 10 % spread between waves).  An item whose
-//     predecessor segment is still in flight is not waited for: the slot keeps its claim and
-//     looks again at its next turn;
+//     accumulation, next work item, next camera ray), classes 1-3 = path vertices by material (hit
+//     record, roulette, light sample, BSDF sample, both BSDF evaluations).  A path that ends inside
+//     a vertex batch is handed to the finisher queue, so every stage runs with its lanes full;
+//   * the WALK stage is a persistent while-while loop whose lanes refill from Q_walk as soon as a
+//     quarter of them is done (shadow ray first, then the path ray of the same vertex), so the box
+//     loop and the primitive loop keep their lanes busy;
+//   * a pixel is bound to a slot for one SEGMENT of its samples only (a sixteenth of them on
+//     config 2): the work items of the global counter are (segment, pixel) pairs in segment-major
+//     order, and between segments the pixel's state (RNG, accumulator) rests in a per-pixel record
+//     in global memory, written and read word by word with agent-scope atomics (data words, then
+//     the tag) by whichever slot draws the next segment.  A frame then ends with the ragged tail
+//     of one segment instead of one whole pixel (config 2 with whole pixels: every wave's last
+//     pixels ran 512 samples in a draining pool, a quarter of the frame at falling efficiency and
+//     10 % spread between waves).  An item whose predecessor segment is still in flight is not
+//     waited for: the slot keeps its claim and looks again at its next turn.
 // Every path still executes exactly the reference's operations in the reference's order with its
 // own RNG stream, so results are bit-identical to render_kernel and to the oracle.
 #pragma once
