@@ -111,6 +111,42 @@ def test_both_render_kernels_give_the_same_bits(scene_name, monkeypatch):
     assert b[1].paths == cst.paths
 
 
+@pytest.mark.parametrize("case", ["config3", "config4", "config5", "big_mesh", "cornell material",
+                                  "feature material", "glass s_normal", "disney g_normal",
+                                  "sphere lights", "const background light"])
+def test_pooled_scheduler_on_every_feature(case, monkeypatch):
+    """Frames of test size go to the lane-bound kernel by policy, so the pooled scheduler is forced
+    here on every feature the path has - image textures with mips, normal and RG maps, env-map and
+    constant-background lights, sphere lights, thin lens, deep trees (the DEEP build), the material
+    and normal integrators - with and without segments, and must give the lane-bound kernel's bits
+    and event counts."""
+    mk = {
+        "config3": lambda: (scenes.config3_scene(res=(96, 72), env=(128, 64)), dict(samples=8, depth=12)),
+        "config4": lambda: (scenes.config4_scene(res=(96, 54), n_lat=48, env=(128, 64)), dict(samples=8, depth=12)),
+        "config5": lambda: (scenes.config5_scene(res=(96, 54), n=64, tex=64), dict(samples=8, depth=12)),
+        "big_mesh": lambda: (scenes.big_mesh_scene(res=(96, 64)), dict(samples=6)),
+        "cornell material": lambda: (scenes.json_scene("cornell_box_spheres.json", res=(80, 80)),
+                                     dict(samples=8, integrator="material", depth=16)),
+        "feature material": lambda: (scenes.feature_scene(res=(72, 48)), dict(samples=6, integrator="material", depth=8)),
+        "glass s_normal": lambda: (scenes.json_scene("glass_in_box.json", res=(96, 72)), dict(samples=4, integrator="s_normal")),
+        "disney g_normal": lambda: (scenes.json_scene("disney_spheres.json", res=(120, 56)), dict(samples=4, integrator="g_normal")),
+        "sphere lights": lambda: (scenes.json_scene("MIS_light_tests/sphere_light_medium_mis.json", res=(64, 64)), dict(samples=16)),
+        "const background light": lambda: (scenes.feature_scene(res=(72, 48), envmap=False, lens=False), dict(samples=6, depth=7)),
+    }[case]
+    s, kw = mk()
+    p = s.default_params(**kw)
+    monkeypatch.setenv("VIMG_HIP_POOL", "0")
+    lane, st_lane = _dev(s).render_to_host(p)
+    for seg in ("1", "3"):
+        monkeypatch.setenv("VIMG_HIP_POOL", "1")
+        monkeypatch.setenv("VIMG_HIP_POOL_SEGMENTS", seg)
+        d = _dev(s)
+        assert d.kernel.startswith("render_pool_kernel")
+        pool, st_pool = d.render_to_host(p)
+        assert np.array_equal(pool.view(np.uint32), lane.view(np.uint32)), (case, seg)
+        assert st_pool.as_dict() == st_lane.as_dict(), (case, seg)
+
+
 @pytest.mark.parametrize("integrator", ["s_normal", "g_normal"])
 def test_normal_integrators_bit_exact(integrator):
     # BASELINE config 1: glass_in_box with the 'normal' integrator (no transcendental on the path)
