@@ -341,10 +341,10 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
     // Segments: the tail of a frame is one segment long, and every hand-over costs a little
     // (config 2, 3.5 pool generations per frame: 1 segment 6.8, 4: 7.5, 8: 7.6, 16-32: 7.6 Grays/s;
     // 3600x1600, 14 generations: 1 segment 7.9, 4: 7.7) - about 56 segments per generation count,
-    // at most 16, of at least 8 samples; frames of 10 generations and more keep their pixels whole
+    // at most 16, of at least 4 samples; frames of 10 generations and more keep their pixels whole
     const double gens = double(items) / double(in_flight);
     uint32_t k = gens >= 10.0 ? 1u : uint32_t(std::min(16.0, std::max(1.0, std::floor(56.0 / gens + 0.5))));
-    k = std::min<uint32_t>(k, std::max<uint32_t>(p->samples / 8u, 1u));
+    k = std::min<uint32_t>(k, std::max<uint32_t>(p->samples / 4u, 1u));
     if (items * 2u < in_flight * 3u) k = 1u;
     if (const char* e = getenv("VIMG_HIP_POOL_SEGMENTS")) k = uint32_t(std::max(1, atoi(e)));
     k = std::min<uint32_t>(k, 4096u);
