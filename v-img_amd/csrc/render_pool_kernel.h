@@ -56,8 +56,10 @@ enum : uint32_t {   // cold records, global memory
   SC_CONE,             // cone width | spread angle | - | -   (textured build only)
   SC_COUNT
 };
-// LDS words per slot and wave: the hot records, five queue rings and the primitive id plane
-constexpr uint32_t POOL_LDS_WORDS = SR_COUNT * 4u + 6u;
+// LDS bytes per slot and wave: the hot records, the primitive id plane and five queue rings of
+// one-byte slot ids (a wave has at most 256 slots)
+constexpr uint32_t POOL_LDS_BYTES = SR_COUNT * 16u + 4u + 5u;
+VD uint32_t pool_wave_bytes(uint32_t slots) { return (POOL_LDS_BYTES * slots + 15u) & ~15u; }
 enum : uint32_t {
   SF_PRIMARY = 1u, SF_NONSPEC = 2u, SF_HAS_S = 4u, SF_HAS_R = 8u, SF_OCCLUDED = 16u,
   SF_FOUND = 32u, SF_FRESH = 64u, SF_KIND_SPHERE = 128u, SF_BOUNCE_SHIFT = 8u
@@ -117,20 +119,20 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
 
   // LDS carve-out of this wave behind the node planes and the four traversal stacks
   VIMG_LDS uint32_t* pool;
-  VIMG_LDS uint32_t* q_walk;
+  VIMG_LDS uint8_t* q_walk;
   VIMG_LDS v4f* lds_leaf;        // copy of leaf_prims (all of them) when A.lds_leaf != 0
   VIMG_LDS uint32_t* q_prim;     // primitive id of the hit, per slot
-  VIMG_LDS uint32_t* q_vertex;   // four rings of capacity P: class 0 finishers, 1 Lambertian (+rest), 2 Principled, 3 other
+  VIMG_LDS uint8_t* q_vertex;    // four rings of capacity P: class 0 finishers, 1 Lambertian (+rest), 2 Principled, 3 other
   {
     const uint32_t node_bytes = (lds_node_bytes(A.lds_nodes) + 255u) & ~255u;
     const uint32_t stack_bytes = 4u * A.stack_entries * 64u * 4u;
-    const uint32_t per_wave = POOL_LDS_WORDS * P;
+    const uint32_t per_wave = pool_wave_bytes(P) / 4u;   // in dwords
     VIMG_LDS uint32_t* base =
         reinterpret_cast<VIMG_LDS uint32_t*>((VIMG_LDS unsigned char*)lds_raw + node_bytes + stack_bytes);
     pool = base + wave * per_wave;
-    q_walk = pool + SR_COUNT * 4u * P;
-    q_prim = q_walk + P;
-    q_vertex = q_prim + P;
+    q_prim = pool + SR_COUNT * 4u * P;
+    q_walk = reinterpret_cast<VIMG_LDS uint8_t*>(q_prim + P);
+    q_vertex = q_walk + P;
     // small scenes: the leaf records behind the four pools (an LDS read instead of an L1 hit per
     // primitive test; the walk is a chain of dependent loads at two waves per SIMD)
     lds_leaf = reinterpret_cast<VIMG_LDS v4f*>(base + 4u * per_wave);
@@ -162,7 +164,7 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
   // every slot starts "fresh": it needs a pixel
   for (uint32_t s = lane; s < P; s += 64) {
     word(SR_RAY, 3, s) = SF_FRESH;
-    q_vertex[s] = s;
+    q_vertex[s] = static_cast<uint8_t>(s);
   }
   qv_count0 = P;
   bool pixels_left = true;   // wave-uniform: the global counter still had work last time
@@ -676,8 +678,8 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
       {
         const bool to_walk = keep && (has_s || has_r), to_fin = keep && !to_walk;
         const unsigned long long mask = __ballot(to_walk), mfin = __ballot(to_fin);
-        if (to_walk) q_walk[ring(qw_head + qw_count + lane_rank(mask, lane))] = slot;
-        if (to_fin) q_vertex[ring(qv_head0 + qv_count0 + lane_rank(mfin, lane))] = slot;
+        if (to_walk) q_walk[ring(qw_head + qw_count + lane_rank(mask, lane))] = static_cast<uint8_t>(slot);
+        if (to_fin) q_vertex[ring(qv_head0 + qv_count0 + lane_rank(mfin, lane))] = static_cast<uint8_t>(slot);
         qw_count += __popcll(mask);
         qv_count0 += __popcll(mfin);
       }
@@ -887,10 +889,11 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
                                    m2 = __ballot(done_item && cls == 2),
                                    m3 = __ballot(done_item && cls == 3);
           if (done_item) {
-            if (cls == 0) q_vertex[ring(qv_head0 + qv_count0 + lane_rank(m0, lane))] = w_slot;
-            else if (cls == 1) q_vertex[P + ring(qv_head1 + qv_count1 + lane_rank(m1, lane))] = w_slot;
-            else if (cls == 2) q_vertex[2 * P + ring(qv_head2 + qv_count2 + lane_rank(m2, lane))] = w_slot;
-            else q_vertex[3 * P + ring(qv_head3 + qv_count3 + lane_rank(m3, lane))] = w_slot;
+            const uint8_t id = static_cast<uint8_t>(w_slot);
+            if (cls == 0) q_vertex[ring(qv_head0 + qv_count0 + lane_rank(m0, lane))] = id;
+            else if (cls == 1) q_vertex[P + ring(qv_head1 + qv_count1 + lane_rank(m1, lane))] = id;
+            else if (cls == 2) q_vertex[2 * P + ring(qv_head2 + qv_count2 + lane_rank(m2, lane))] = id;
+            else q_vertex[3 * P + ring(qv_head3 + qv_count3 + lane_rank(m3, lane))] = id;
             w_slot = SLOT_IDLE;
           }
           qv_count0 += __popcll(m0);

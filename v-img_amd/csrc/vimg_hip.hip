@@ -303,7 +303,7 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   if (c.pooled) {
     // the pool takes what is left of this workgroup's share of the CU's 160 KiB
     const uint32_t share = (160u * 1024u) / uint32_t(c.wps) - 1024u;
-    const uint32_t per_slot = POOL_LDS_WORDS * 4u * 4u;   // LDS bytes per slot, all four waves
+    const uint32_t per_slot = POOL_LDS_BYTES * 4u;   // LDS bytes per slot, all four waves
     // small scenes: all leaf records in LDS too (they cost a few slots, the walk gains more)
     uint32_t leaf_bytes = 0;
     a.lds_leaf = 0;
@@ -311,12 +311,12 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
       a.lds_leaf = s->num_leaf_prims;
       leaf_bytes = a.lds_leaf * 48u;
     }
-    uint32_t slots = share > c.lds_bytes + leaf_bytes ? (share - c.lds_bytes - leaf_bytes) / per_slot : 0;
+    uint32_t slots = share > c.lds_bytes + leaf_bytes + 64u ? (share - c.lds_bytes - leaf_bytes - 64u) / per_slot : 0;
     slots = std::min(slots, 256u);
     if (const char* e = getenv("VIMG_HIP_POOL_SLOTS")) slots = std::min(slots, uint32_t(atoi(e)));
     if (const char* e = getenv("VIMG_HIP_POOL_REFILL")) a.pool_refill = uint32_t(std::max(1, atoi(e)));
     a.pool_slots = std::max(slots, 8u);
-    c.lds_bytes += a.pool_slots * per_slot + leaf_bytes;
+    c.lds_bytes += 4u * ((POOL_LDS_BYTES * a.pool_slots + 15u) & ~15u) + leaf_bytes;
   }
   // persistent grid: as many 4-wave workgroups as the kernel's registers and LDS let a CU hold
   // (asked of the runtime), never more than the work
