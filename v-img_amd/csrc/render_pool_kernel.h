@@ -745,10 +745,14 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
         if (!__any(w_slot != SLOT_IDLE)) break;
         // (3) walk until a quarter of the wave has a finished ray (or nothing is left to walk)
         for (;;) {
+          // the box loop in two builds: rays with a zero direction component need the exact
+          // select form of the slab test (0 * inf); a round without such a ray runs the build
+          // that has only the min/max form
+          auto box_loop = [&](auto exact_possible) {
           while (cur != REF_DONE && ref_count(cur) == 0) {
             v4f na, nb, nc;
             v2u refs;
-            if (cur < L.n_nodes) {
+            if (!DEEP || cur < L.n_nodes) {   // the build for trees that fit has every node in LDS
               na = L.na[cur], nb = L.nb[cur], nc = L.nc[cur];
               refs = L.nm[cur];
             } else {
@@ -761,7 +765,7 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
               if (first_active_lane()) cnt.trip_descend++;
             }
             float h1, h2;
-            if (w_exact) {
+            if (decltype(exact_possible)::value && w_exact) {
               h1 = slab(f3{na.x, na.y, na.z}, f3{na.w, nb.x, nb.y}, ray.o, w_inv, ray.min_t, ray.max_t);
               h2 = slab(f3{nb.z, nb.w, nc.x}, f3{nc.y, nc.z, nc.w}, ray.o, w_inv, ray.min_t, ray.max_t);
             } else {
@@ -791,6 +795,11 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
               if (__popcll(__ballot(cur != REF_DONE && ref_count(cur) == 0)) < box_min) break;
             }
           }
+          };
+          if (__any(w_exact && w_slot != SLOT_IDLE))
+            box_loop(std::true_type{});
+          else
+            box_loop(std::false_type{});
           PROF_LAP(PF_W_BOX)
           if (cur != REF_DONE && (!DEEP || ref_count(cur) != 0)) {
             const uint32_t first = ref_index(cur), count = ref_count(cur);

@@ -296,7 +296,7 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   // 40: 1.15 / 1.93 Grays/s
   a.pool_boxmin = 16;
   if (const char* e = getenv("VIMG_HIP_POOL_BOXMIN")) a.pool_boxmin = uint32_t(std::min(64, std::max(0, atoi(e))));
-  c.deep = c.pooled && a.lds_nodes < s->d.num_nodes && a.pool_boxmin != 0;
+  c.deep = c.pooled && a.lds_nodes < s->d.num_nodes;   // the other build reads every node from LDS
   if (const char* e = getenv("VIMG_HIP_POOL_STARVE")) a.pool_starve = uint32_t(std::min(64, std::max(1, atoi(e))));
   if (const char* e = getenv("VIMG_HIP_POOL_VBATCH")) a.pool_vbatch = uint32_t(std::min(64, std::max(1, atoi(e))));
   if (const char* e = getenv("VIMG_HIP_POOL_CLASSES")) a.pool_classes = uint32_t(std::min(3, std::max(1, atoi(e))));
