@@ -101,6 +101,8 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
   const Lds L = stage_lds(g, A, (VIMG_LDS unsigned char*)lds_raw);
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool full_stats = A.full_stats != 0;
+  // event counters of the walk without a branch in the loops: += 1 or += 0 (wave-uniform)
+  const uint32_t stat_inc = full_stats ? 1u : 0u;
   const uint32_t W = static_cast<uint32_t>(g.res_x), H = static_cast<uint32_t>(g.res_y);
   const bool single = A.single_x >= 0;
   const uint32_t total_items = single ? 1u : A.num_local_tiles * 64u;
@@ -760,10 +762,10 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
               na = nd->a, nb = nd->b, nc = nd->c;
               refs = v2u{nd->left_ref, nd->right_ref};
             }
-            if (full_stats) {
-              cnt.internal++;
-              if (first_active_lane()) cnt.trip_descend++;
-            }
+            cnt.internal += stat_inc;
+#ifdef VIMG_PROFILE
+            if (full_stats && first_active_lane()) cnt.trip_descend++;
+#endif
             float h1, h2;
             if (decltype(exact_possible)::value && w_exact) {
               h1 = slab(f3{na.x, na.y, na.z}, f3{na.w, nb.x, nb.y}, ray.o, w_inv, ray.min_t, ray.max_t);
@@ -803,7 +805,7 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
           PROF_LAP(PF_W_BOX)
           if (cur != REF_DONE && (!DEEP || ref_count(cur) != 0)) {
             const uint32_t first = ref_index(cur), count = ref_count(cur);
-            if (full_stats) cnt.leaf++;
+            cnt.leaf += stat_inc;
             bool stop = false;
             for (uint32_t i = 0; i < count && !stop; ++i) {
               gptr<DLeafPrim> lp = g.leaf_prims + (first + i);
@@ -818,17 +820,17 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
               const float c0 = c.x;
               const uint32_t lp_prim = __float_as_uint(c.y), kind = __float_as_uint(c.z),
                              lp_cls = __float_as_uint(c.w);   // DLeafPrim: c0 | prim | kind | cls
-              if (full_stats) {
-                cnt.prim++;
-                if (first_active_lane()) cnt.trip_prim++;
-              }
+              cnt.prim += stat_inc;
+#ifdef VIMG_PROFILE
+              if (full_stats && first_active_lane()) cnt.trip_prim++;
+#endif
               bool hit = false;
               float t = 0.f, e0 = 0.f, e1 = 0.f, e2 = 0.f, idet = 0.f;
               if (kind == 0) {
                 hit = tri_test(f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c0}, ray, rc, t, e0,
                                e1, e2, idet);
               } else if (kind == 1) {
-                if (full_stats) cnt.sphere++;
+                cnt.sphere += stat_inc;
                 hit = sphere_test(f3{a.x, a.y, a.z}, a.w, ray, w_dir_len2, t);
               }
               if (hit) {
