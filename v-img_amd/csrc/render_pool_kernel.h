@@ -762,6 +762,8 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
               na = nd->a, nb = nd->b, nc = nd->c;
               refs = v2u{nd->left_ref, nd->right_ref};
             }
+            const uint32_t sp_below = sp != 0 ? sp - 1 : 0u;
+            const uint32_t popped = L.stack[sp_below * 64];
             cnt.internal += stat_inc;
 #ifdef VIMG_PROFILE
             if (full_stats && first_active_lane()) cnt.trip_descend++;
@@ -776,21 +778,17 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
             }
             const bool in1 = !is_inf(h1), in2 = !is_inf(h2);
             const uint32_t c1 = refs.x, c2 = refs.y;
-            if (in1 && in2) {
-              const bool first_is_near = w_any ? false : (h2 > h1);
-              const uint32_t near_c = first_is_near ? c1 : c2;
-              const uint32_t far_c = first_is_near ? c2 : c1;
-              L.stack[sp * 64] = far_c;
-              ++sp;
-              cur = near_c;
-            } else if (in1 || in2) {
-              cur = in1 ? c1 : c2;
-            } else if (sp != 0) {
-              --sp;
-              cur = L.stack[sp * 64];
-            } else {
-              cur = REF_DONE;
-            }
+            // branch-free step: the entry a pop would return was read before the box test (its
+            // latency hides behind the test); the far child is written above the top of the stack
+            // whether it is kept or not (the slot is free), and sp moves by select
+            const bool both = in1 && in2, any = in1 || in2;
+            const bool first_is_near = w_any ? false : (h2 > h1);
+            const uint32_t near_c = first_is_near ? c1 : c2;
+            const uint32_t far_c = first_is_near ? c2 : c1;
+            L.stack[sp * 64] = far_c;
+            const uint32_t one_c = in1 ? c1 : c2;
+            cur = both ? near_c : (any ? one_c : (sp != 0 ? popped : REF_DONE));
+            sp = both ? sp + 1 : (any ? sp : sp_below);
             // deep trees: when only a few lanes still descend, the lanes that wait at a leaf go
             // first (the box loop of the config-5 stand-in ran with 27 % of its lanes busy)
             if constexpr (DEEP) {
