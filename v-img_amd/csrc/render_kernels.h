@@ -457,6 +457,43 @@ VD bool tri_test(f3 p0, f3 p1, f3 p2, const TravRay& ray, const TriRayConst& rc,
   e0o = e0, e1o = e1, e2o = e2, inv_det_o = inv_det;
   return true;
 }
+// The same test with its rejections folded into one predicate (one exec-mask region for the
+// hit instead of one per early return: the primitive loop of the walk is dominated by mask
+// bookkeeping otherwise).  Comparisons keep the reference's form, so NaN operands take the same
+// way out (every ordered comparison false -> accepted, as in the reference).
+VD bool tri_test_flat(f3 p0, f3 p1, f3 p2, const TravRay& ray, const TriRayConst& rc, float& t_out,
+                      float& e0o, float& e1o, float& e2o, float& inv_det_o) {
+  f3 p0t = permute(p0 - ray.o, rc.kz);
+  f3 p1t = permute(p1 - ray.o, rc.kz);
+  f3 p2t = permute(p2 - ray.o, rc.kz);
+  p0t.x += rc.sx * p0t.z;
+  p0t.y += rc.sy * p0t.z;
+  p1t.x += rc.sx * p1t.z;
+  p1t.y += rc.sy * p1t.z;
+  p2t.x += rc.sx * p2t.z;
+  p2t.y += rc.sy * p2t.z;
+  float e0 = diff_of_products(p1t.x, p2t.y, p1t.y, p2t.x);
+  float e1 = diff_of_products(p2t.x, p0t.y, p2t.y, p0t.x);
+  float e2 = diff_of_products(p0t.x, p1t.y, p0t.y, p1t.x);
+  if (e0 == 0.f || e1 == 0.f || e2 == 0.f) {
+    e0 = diff_of_products_double(p1t.x, p2t.y, p1t.y, p2t.x);
+    e1 = diff_of_products_double(p2t.x, p0t.y, p2t.y, p0t.x);
+    e2 = diff_of_products_double(p0t.x, p1t.y, p0t.y, p1t.x);
+  }
+  const bool mixed = (e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0);
+  const float det = e0 + e1 + e2;
+  const float t_scaled = e0 * (p0t.z * rc.sz) + e1 * (p1t.z * rc.sz) + e2 * (p2t.z * rc.sz);
+  const float hi = ray.max_t * det, lo = ray.min_t * det;
+  const bool out_neg = det < 0 && (t_scaled >= 0 || t_scaled < hi || t_scaled > lo);
+  const bool out_pos = det > 0 && (t_scaled <= 0 || t_scaled > hi || t_scaled < lo);
+  const bool hit = !mixed && !(det == 0) && !out_neg && !out_pos;
+  if (hit) {
+    const float inv_det = 1.f / det;
+    t_out = t_scaled * inv_det;
+    e0o = e0, e1o = e1, e2o = e2, inv_det_o = inv_det;
+  }
+  return hit;
+}
 // Sphere::sphere_hit_template + solveQuadratic: reference include/geometry/sphere.h:13-100.
 // `q` is a double there (unqualified sqrt) — kept, FP64 is half rate on this chip.
 VD bool sphere_test(f3 center, float radius, const TravRay& r, float a, float& t_out) {

@@ -825,8 +825,8 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
               bool hit = false;
               float t = 0.f, e0 = 0.f, e1 = 0.f, e2 = 0.f, idet = 0.f;
               if (kind == 0) {
-                hit = tri_test(f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c0}, ray, rc, t, e0,
-                               e1, e2, idet);
+                hit = tri_test_flat(f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c0}, ray, rc, t, e0,
+                                    e1, e2, idet);
               } else if (kind == 1) {
                 cnt.sphere += stat_inc;
                 hit = sphere_test(f3{a.x, a.y, a.z}, a.w, ray, w_dir_len2, t);
