@@ -831,27 +831,22 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
                 cnt.sphere += stat_inc;
                 hit = sphere_test(f3{a.x, a.y, a.z}, a.w, ray, w_dir_len2, t);
               }
-              if (hit) {
-                ray.max_t = t;
-                w_found = true;
-                if (w_any) {
-                  stop = true;   // exit on first hit
-                } else {
-                  rec.e0 = e0, rec.e1 = e1, rec.e2 = e2, rec.inv_det = idet;
-                  rec.prim = lp_prim;
-                  rec.kind = kind;
-                  w_cls = lp_cls;
-                }
-              }
+              // by select: a hit shortens the ray; an any-hit ray stops at its first hit, a
+              // closest-hit ray keeps the record of the last success
+              ray.max_t = hit ? t : ray.max_t;
+              w_found = w_found || hit;
+              stop = hit && w_any;
+              const bool keep_rec = hit && !w_any;
+              rec.e0 = keep_rec ? e0 : rec.e0, rec.e1 = keep_rec ? e1 : rec.e1;
+              rec.e2 = keep_rec ? e2 : rec.e2, rec.inv_det = keep_rec ? idet : rec.inv_det;
+              rec.prim = keep_rec ? lp_prim : rec.prim;
+              rec.kind = keep_rec ? kind : rec.kind;
+              w_cls = keep_rec ? lp_cls : w_cls;
             }
-            if (stop) {
-              cur = REF_DONE;
-            } else if (sp != 0) {
-              --sp;
-              cur = L.stack[sp * 64];
-            } else {
-              cur = REF_DONE;
-            }
+            const uint32_t sp_below = sp != 0 ? sp - 1 : 0u;
+            const uint32_t popped = L.stack[sp_below * 64];
+            cur = (stop || sp == 0) ? REF_DONE : popped;
+            sp = sp_below;
           }
           PROF_LAP(PF_W_LEAF)
           const uint32_t n_fin = __popcll(__ballot(w_slot != SLOT_IDLE && cur == REF_DONE));
