@@ -572,8 +572,10 @@ VD bool traverse(const DScene& g, const Lds& L, TravRay& ray, HitRec& rec, Count
   uint32_t sp = 0;
   uint32_t cur = g.root_ref;
   bool found = false;
-  while (cur != REF_DONE) {
-    // ---- descend: box tests until this lane holds a leaf
+  const uint32_t stat_inc = full_stats ? 1u : 0u;   // event counters without a branch in the loops
+  // the box loop in two builds (see render_pool_kernel.h): only a wave that carries a ray with a
+  // zero direction component runs the one with the exact select form of the slab test
+  auto box_loop = [&](auto exact_possible) {
     while (cur != REF_DONE && ref_count(cur) == 0) {
       v4f na, nb, nc;
       v2u refs;
@@ -585,12 +587,11 @@ VD bool traverse(const DScene& g, const Lds& L, TravRay& ray, HitRec& rec, Count
         na = n->a, nb = n->b, nc = n->c;
         refs = v2u{n->left_ref, n->right_ref};
       }
-      if (full_stats) {
-        cnt.internal++;
-        if (first_active_lane()) cnt.trip_descend++;
-      }
+      const uint32_t sp_below = sp != 0 ? sp - 1 : 0u;
+      const uint32_t popped = L.stack[sp_below * 64];   // what a pop would return, read ahead
+      cnt.internal += stat_inc;
       float h1, h2;
-      if (exact_slab) {
+      if (decltype(exact_possible)::value && exact_slab) {
         h1 = slab(f3{na.x, na.y, na.z}, f3{na.w, nb.x, nb.y}, ray.o, inv, ray.min_t, ray.max_t);
         h2 = slab(f3{nb.z, nb.w, nc.x}, f3{nc.y, nc.z, nc.w}, ray.o, inv, ray.min_t, ray.max_t);
       } else {
@@ -599,42 +600,39 @@ VD bool traverse(const DScene& g, const Lds& L, TravRay& ray, HitRec& rec, Count
       }
       const bool in1 = !is_inf(h1), in2 = !is_inf(h2);
       const uint32_t c1 = refs.x, c2 = refs.y;
-      if (in1 && in2) {
-        const bool first_is_near = ANY_HIT ? false : (h2 > h1);
-        const uint32_t near_c = first_is_near ? c1 : c2;
-        const uint32_t far_c = first_is_near ? c2 : c1;
-        L.stack[sp * 64] = far_c;
-        ++sp;
-        cur = near_c;
-      } else if (in1 || in2) {
-        cur = in1 ? c1 : c2;
-      } else if (sp != 0) {
-        --sp;
-        cur = L.stack[sp * 64];
-      } else {
-        cur = REF_DONE;
-      }
+      const bool both = in1 && in2, any = in1 || in2;
+      const bool first_is_near = ANY_HIT ? false : (h2 > h1);
+      const uint32_t near_c = first_is_near ? c1 : c2;
+      const uint32_t far_c = first_is_near ? c2 : c1;
+      L.stack[sp * 64] = far_c;   // above the top of the stack: kept only when both were hit
+      const uint32_t one_c = in1 ? c1 : c2;
+      cur = both ? near_c : (any ? one_c : (sp != 0 ? popped : REF_DONE));
+      sp = both ? sp + 1 : (any ? sp : sp_below);
     }
+  };
+  while (cur != REF_DONE) {
+    // ---- descend: box tests until this lane holds a leaf
+    if (__any(exact_slab))
+      box_loop(std::true_type{});
+    else
+      box_loop(std::false_type{});
     // ---- intersect the leaf this lane holds
     if (cur != REF_DONE) {
       const uint32_t first = ref_index(cur), count = ref_count(cur);
-      if (full_stats) cnt.leaf++;
+      cnt.leaf += stat_inc;
       for (uint32_t i = 0; i < count; ++i) {
         gptr<DLeafPrim> lp = g.leaf_prims + (first + i);
         const v4f a = lp->a, b = lp->b;
         const float c0 = lp->c0;
         const uint32_t kind = lp->kind;
-        if (full_stats) {
-          cnt.prim++;
-          if (first_active_lane()) cnt.trip_prim++;
-        }
+        cnt.prim += stat_inc;
         bool hit = false;
         float t = 0.f, e0 = 0.f, e1 = 0.f, e2 = 0.f, idet = 0.f;
         if (kind == 0) {
-          hit = tri_test(f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c0}, ray, rc, t, e0, e1,
-                         e2, idet);
+          hit = tri_test_flat(f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c0}, ray, rc, t, e0,
+                              e1, e2, idet);
         } else if (kind == 1) {
-          if (full_stats) cnt.sphere++;
+          cnt.sphere += stat_inc;
           hit = sphere_test(f3{a.x, a.y, a.z}, a.w, ray, dir_len2, t);
         }
         if (hit) {
