@@ -480,7 +480,7 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
         // both BSDF evaluations happen before either ray is traced: the evaluation towards the
         // light is pure, so doing it for a light that turns out occluded changes nothing; its
         // regularisation flag is the one from BEFORE this bounce
-#pragma unroll 1
+#pragma unroll
         for (int k = 0; k < 2; ++k) {
           const bool run = (k == 0) ? nee : sc.valid;
           if (run) {
