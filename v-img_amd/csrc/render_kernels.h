@@ -1120,10 +1120,11 @@ VD void principled_eval_pdf(const DScene& g, gptr<VimgMaterial> m, f3 wi,
   f_out = eval_principled;
 }
 
-template <bool TEX>
+// MT: material type known at compile time (a batch of one material class), -1 = read it
+template <bool TEX, int MT = -1>
 VD Scatter sample_mat(const DScene& g, const Hit& hit, f3 wi, Rng& rng, bool regularize) {
   gptr<VimgMaterial> m = g.materials + hit.mat;
-  const uint32_t type = m->type;
+  const uint32_t type = MT >= 0 ? uint32_t(MT) : m->type;
   const f3 dir_in = -wi;
   uint32_t lobe = LOBE_NONE;
   Onb frame{f3{1.f, 0.f, 0.f}, f3{0.f, 1.f, 0.f}, f3{0.f, 0.f, 1.f}};
@@ -1277,11 +1278,11 @@ VD Scatter sample_mat(const DScene& g, const Hit& hit, f3 wi, Rng& rng, bool reg
 }
 // Material::eval_pdf_pair dispatch; the base class returns (0, 1) (material.h:56-60), which is
 // what Dielectric and DiffuseLight inherit
-template <bool TEX>
+template <bool TEX, int MT = -1>
 VD void eval_pdf_pair(const DScene& g, const Hit& hit, f3 wi, f3 wo, RayCone cone, bool regularize,
                       f3& f, float& pdf) {
   gptr<VimgMaterial> m = g.materials + hit.mat;
-  const uint32_t type = m->type;
+  const uint32_t type = MT >= 0 ? uint32_t(MT) : m->type;
   if (type == VIMG_MAT_LAMBERTIAN) {
     // Lambertian::eval_pdf_pair, reference src/material/lambertian.cpp:47-54
     float dot_product = static_cast<float>(sel_max(0.0f, dot(wo, hit.ns)) / kPi);

@@ -442,9 +442,14 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
         }
         at_vertex = false;
       }
-      if (at_vertex) {
+      // A batch of class 1 holds Lambertian vertices only and one of class 2 Principled ones only
+      // (three-class sorting), so the shading code exists in a build per material with the type
+      // dispatch folded away - the Lambertian build carries none of the Disney lobes' registers -
+      // and a generic build for everything else.
+      auto shade_vertex = [&](auto mt_tag) {
+        constexpr int MT = decltype(mt_tag)::value;
         // mis_integrator.cpp:45-122.  Draw order: light pick + emitter sample, then sample_mat.
-        const uint32_t mat_type = g.materials[hit.mat].type;
+        const uint32_t mat_type = MT >= 0 ? uint32_t(MT) : g.materials[hit.mat].type;
         float hit_dist = 0.f, surface_spread_angle = 0.f;
         if constexpr (TEX) {
           hit_dist = length(ray_o - hit.p);
@@ -461,7 +466,7 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
         PROF_LAP(PF_V_LIGHT)
         const bool reg_before = non_specular_bounce;
         RayCone nee_cone = cone;
-        Scatter sc = sample_mat<TEX>(g, hit, ray_d, rng, reg_before);
+        Scatter sc = sample_mat<TEX, MT>(g, hit, ray_d, rng, reg_before);
         PROF_LAP(PF_V_SAMPLE)
         if constexpr (TEX) {
           nee_cone = propagate_reflect_cone(cone, surface_spread_angle * 2.f, hit_dist);
@@ -489,7 +494,7 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
             const f3 wo = (k == 0) ? li.wi : sc.wo;
             const RayCone c = (k == 0) ? nee_cone : cone;
             const bool reg = (k == 0) ? reg_before : non_specular_bounce;
-            eval_pdf_pair<TEX>(g, hit, ray_d, wo, c, reg, f, pdf);
+            eval_pdf_pair<TEX, MT>(g, hit, ray_d, wo, c, reg, f, pdf);
             if (k == 0) {
               if (pdf != 0 && !is_nan(pdf)) {
                 float G = li.G;
@@ -517,6 +522,14 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
         ray_d = sc.wo;
         primary = false;
         if (!has_s && !has_r) finish = true;
+      };
+      if (at_vertex) {
+        if (A.pool_classes == 3u && cls == 1u)
+          shade_vertex(std::integral_constant<int, int(VIMG_MAT_LAMBERTIAN)>{});
+        else if (A.pool_classes == 3u && cls == 2u)
+          shade_vertex(std::integral_constant<int, int(VIMG_MAT_PRINCIPLED)>{});
+        else
+          shade_vertex(std::integral_constant<int, -1>{});
       }
 
       // ---- finished samples: accumulate, pixel write-back, next pixel, next camera ray
