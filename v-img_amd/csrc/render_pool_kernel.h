@@ -577,7 +577,11 @@ render_pool_kernel(const DScene g, const RenderArgs A, float* __restrict__ out,
           state_store(st + 4, fu(acc.x));
           state_store(st + 5, fu(acc.y));
           state_store(st + 6, fu(acc.z));
+          // the data words must have been performed before the tag is: wait for the wave's
+          // outstanding vector stores (a workgroup-scope release fence compiles to a wait on the
+          // LDS / scalar counter only), then store the tag
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt and lgkmcnt untouched
           state_store(st + 2, A.pool_epoch + smp / seg_len);
           need_pixel = true;
         }
