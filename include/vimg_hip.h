@@ -61,7 +61,10 @@ int vimg_hip_render(VimgDeviceScene* scene, const VimgRenderParams* params, void
                     void* stream, VimgRenderStats* stats);
 
 /* Same as vimg_hip_render but only enqueues (no host wait, no stats); used by bench.py to time
- * back-to-back launches with HIP events on `stream`. */
+ * back-to-back launches with HIP events on `stream`.  A scene renders one frame at a time: its
+ * work counter and the scheduler's scratch (path-slot records, per-pixel records) are owned by the
+ * scene, so launches on the same scene must be ordered on one stream.  A kernel-side failure (the
+ * scheduler's watchdog) is reported by the next blocking call on the scene, not by this one. */
 int vimg_hip_render_async(VimgDeviceScene* scene, const VimgRenderParams* params, void* d_out_rgb,
                           void* stream);
 
