@@ -19,7 +19,7 @@ ORAHDR  := $(wildcard oracle/*.h) $(wildcard include/*.h)
 # multiply-adds appear only where the reference writes std::fma.
 HOSTFLAGS := -std=c++20 -O2 -fPIC -shared -ffp-contract=off -fopenmp -Wall -Iinclude
 ORAFLAGS  := -std=c++20 -O3 -march=x86-64-v3 -fPIC -shared -ffp-contract=off -pthread -Wall -Iinclude
-HIPFLAGS  := --offload-arch=$(ARCH) -std=c++20 -O3 -fPIC -shared -ffp-contract=off \
+HIPFLAGS  := --offload-arch=$(ARCH) -std=c++20 -O3 -fPIC -shared -ffp-contract=off -fno-slp-vectorize \
              -fno-fast-math -Iinclude -Wall -Wno-unused-function
 
 all: host hip oracle cli
