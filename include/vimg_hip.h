@@ -132,6 +132,17 @@ int vimg_hip_lut8_to_float(const uint8_t* in, uint64_t n, const float* lut256, f
 /* convert_RGB_to_normal: normalize((rgb / 127.5 - 1) * (scale, scale, 1)) per pixel. */
 int vimg_hip_rgb8_to_normal(const uint8_t* rgb8, uint64_t n_pixels, float scale, float* out_xyz);
 
+/* ---- GPU BVH builder ---------------------------------------------------
+ * A linear BVH (Morton order, Karras' radix tree, bottom-up boxes; one primitive per leaf) in the
+ * reference's layout (include/bvh.h:22-57).  Not the reference's SAH builders (those stay on the
+ * host, vimg_host_build_bvh): for geometry that changes between frames.  Host buffers:
+ *   bounds6     : n x {min.xyz, max.xyz} of the primitives, in list_objects order
+ *   nodes       : capacity 2n - 1;   bb : capacity (2 (2n - 1) + 3) float triples;
+ *   obj_indices : n entries.
+ * Has the signature vimg_host_build_bvh_with() takes. */
+int vimg_hip_build_lbvh(uint32_t n, const float* bounds6, uint32_t* num_nodes, uint32_t* max_depth,
+                        VimgBVHNode* nodes, float* bb, uint32_t* obj_indices);
+
 /* Name of the render kernel this scene is launched with (the upload picks the build: textured or
  * not, register budget, lane-bound or pooled scheduler) - what a rocprofv3 kernel trace will show. */
 const char* vimg_hip_scene_kernel(const VimgDeviceScene* scene);

@@ -86,6 +86,13 @@ void vimg_host_rgb8_to_normal(const uint8_t* rgb8, uint64_t n_pixels, float scal
  * leaf as src/main.cpp:200; binned: 16 bins as src/main.cpp:41). */
 int vimg_host_build_bvh(VimgHostScene* s, int bvh_type);
 
+/* The same with a caller-supplied builder (libvimg_hip's vimg_hip_build_lbvh has this signature):
+ * it receives the primitive bounds the host builders use and fills the reference's BVH arrays. */
+typedef int (*vimg_bvh_builder_fn)(uint32_t n, const float* bounds6, uint32_t* num_nodes,
+                                   uint32_t* max_depth, VimgBVHNode* nodes, float* bb,
+                                   uint32_t* obj_indices);
+int vimg_host_build_bvh_with(VimgHostScene* s, vimg_bvh_builder_fn builder);
+
 /* View valid until the scene is modified or freed.  NULL before vimg_host_build_bvh. */
 const VimgScene* vimg_host_scene_view(const VimgHostScene* s);
 void vimg_host_default_params(const VimgHostScene* s, VimgRenderParams* out);

@@ -239,6 +239,107 @@ def test_bvh_invariants(kind):
     assert seen.all()
 
 
+def _check_tree(s, leaf_max):
+    """Invariants of the reference's BVH layout: every primitive in exactly one leaf, every box
+    holds what hangs below it, siblings adjacent, max_depth = levels.  Returns the depth found."""
+    nodes, bb, obj, depth = s.bvh_arrays()
+    v = s.view.contents
+    n_prims = v.num_prims
+    assert sorted(obj.tolist()) == list(range(n_prims))
+    verts = np.ctypeslib.as_array(v.vertices, (v.num_vertices, 3)) if v.num_vertices else None
+    lo = np.zeros((n_prims, 3), np.float32)
+    hi = np.zeros((n_prims, 3), np.float32)
+    for i in range(n_prims):
+        pr = v.prims[i]
+        if pr.type == abi.PRIM_TRIANGLE:
+            m = v.meshes[v.tri_mesh[pr.index]]
+            idx = [m.first_vertex + v.tri_indices[pr.index * 3 + k] for k in range(3)]
+            lo[i], hi[i] = verts[idx].min(0), verts[idx].max(0)
+        else:
+            sp = v.spheres[pr.index]
+            c = np.array(list(sp.center), np.float32)
+            lo[i], hi[i] = c - sp.radius, c + sp.radius
+    seen = np.zeros(len(nodes), bool)
+    stack = [(0, bb[0], bb[2], 1)]
+    deepest = 0
+    while stack:
+        n, box_lo, box_hi, d = stack.pop()
+        assert not seen[n]
+        seen[n] = True
+        deepest = max(deepest, d)
+        first, count = int(nodes[n][0]), int(nodes[n][1])
+        if count:
+            assert count <= leaf_max
+            ids = obj[first:first + count]
+            assert np.all(lo[ids] >= box_lo) and np.all(hi[ids] <= box_hi)
+            continue
+        base = 2 * first + 2
+        for k in (0, 1):
+            c_lo, c_hi = bb[base + k], bb[base + 2 + k]
+            assert np.all(c_lo >= box_lo) and np.all(c_hi <= box_hi)
+            stack.append((first + k, c_lo, c_hi, d + 1))
+    assert seen.all() and deepest == depth
+    return depth
+
+
+def test_build_bvh_with_a_supplied_builder():
+    """vimg_host_build_bvh_with: the builder gets the primitive bounds the host builders use and
+    fills the reference's arrays; here a median-split builder written in Python.  The image does
+    not depend on the tree (different trees only reorder the tests; ties aside)."""
+    import oracle_lib as O
+    BUILDER = C.CFUNCTYPE(C.c_int, C.c_uint32, abi.Pf32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                          C.c_void_p, abi.Pf32, C.POINTER(C.c_uint32))
+
+    def median_split(n, bounds6, num_nodes, max_depth, nodes_p, bb_p, obj_p):
+        b = np.ctypeslib.as_array(bounds6, (n, 6)).copy()
+        nodes = np.ctypeslib.as_array(C.cast(nodes_p, C.POINTER(C.c_uint32)), (2 * n - 1, 2))
+        bb = np.ctypeslib.as_array(bb_p, (2 * (2 * n - 1) + 3, 3))
+        obj = np.ctypeslib.as_array(obj_p, (n,))
+        centre = (b[:, :3] + b[:, 3:]) * 0.5
+        state = {"next": 1, "pos": 0, "depth": 0}
+
+        def box(ids):
+            return b[ids, :3].min(0), b[ids, 3:].max(0)
+
+        def build(node, ids, d):
+            state["depth"] = max(state["depth"], d)
+            if len(ids) <= 2:
+                nodes[node] = (state["pos"], len(ids))
+                obj[state["pos"]:state["pos"] + len(ids)] = ids
+                state["pos"] += len(ids)
+                return
+            lo, hi = box(ids)
+            axis = int(np.argmax(hi - lo))
+            order = ids[np.argsort(centre[ids, axis], kind="stable")]
+            halves = (order[:len(ids) // 2], order[len(ids) // 2:])
+            first = state["next"]
+            state["next"] += 2
+            nodes[node] = (first, 0)
+            for k in (0, 1):
+                c_lo, c_hi = box(halves[k])
+                bb[2 * first + 2 + k], bb[2 * first + 4 + k] = c_lo, c_hi
+            build(first, halves[0], d + 1)
+            build(first + 1, halves[1], d + 1)
+
+        ids = np.arange(n)
+        bb[0], bb[2] = box(ids)
+        build(0, ids, 1)
+        num_nodes[0], max_depth[0] = state["next"], state["depth"]
+        return 0
+
+    cb = BUILDER(median_split)
+    s = scenes.json_scene("cornell_box_spheres.json", res=(48, 48))
+    p = s.default_params(samples=4)
+    ref, _, _ = O.render(s, p, threads=2)
+    s.build_bvh_with(C.cast(cb, C.c_void_p))
+    assert _check_tree(s, leaf_max=2) >= 3
+    img, _, _ = O.render(s, p, threads=2)
+    same = (img.view(np.uint32) == ref.view(np.uint32)).all(axis=-1).mean()
+    assert same > 0.98 and abs(img.mean() - ref.mean()) < 0.02 * ref.mean()
+    with pytest.raises(host.HostError, match="builder failed"):
+        s.build_bvh_with(C.cast(BUILDER(lambda *a: -1), C.c_void_p))
+
+
 # ------------------------------------------------------------------------------- textures / env
 def test_mip_chain_and_env_cdfs():
     s = scenes.feature_scene()

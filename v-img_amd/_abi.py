@@ -153,6 +153,7 @@ HOST_SYMBOLS = {
     "vimg_host_srgb8_to_linear": (None, [C.POINTER(C.c_uint8), C.c_uint64, Pf32]),
     "vimg_host_rgb8_to_normal": (None, [C.POINTER(C.c_uint8), C.c_uint64, f32, Pf32]),
     "vimg_host_build_bvh": (C.c_int, [C.c_void_p, C.c_int]),
+    "vimg_host_build_bvh_with": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vimg_host_scene_view": (PScene, [C.c_void_p]),
     "vimg_host_default_params": (None, [C.c_void_p, PParams]),
     "vimg_host_tonemap_to_rgb8": (C.c_int, [Pf32, C.c_int, C.c_int, C.c_int,
@@ -183,6 +184,8 @@ HIP_SYMBOLS = {
     "vimg_hip_build_env_cdfs": (C.c_int, [Pf32, u32, u32, Pf32, Pf32]),
     "vimg_hip_lut8_to_float": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint64, Pf32, Pf32]),
     "vimg_hip_rgb8_to_normal": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint64, f32, Pf32]),
+    "vimg_hip_build_lbvh": (C.c_int, [u32, Pf32, C.POINTER(u32), C.POINTER(u32), C.c_void_p, Pf32,
+                                     C.POINTER(u32)]),
     "vimg_hip_scene_bytes": (i64, [C.c_void_p]),
     "vimg_hip_scene_kernel": (C.c_char_p, [C.c_void_p]),
     "vimg_hip_last_error": (C.c_char_p, []),

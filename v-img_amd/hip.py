@@ -231,3 +231,8 @@ def install_gpu_precompute(enable=True):
     lib = abi.hip_lib()
     host.vimg_host_set_precompute(C.cast(lib.vimg_hip_build_mip_chain, C.c_void_p),
                                   C.cast(lib.vimg_hip_build_env_cdfs, C.c_void_p))
+
+
+def lbvh_builder():
+    """Function pointer of the GPU LBVH builder for HostScene.build_bvh_with()."""
+    return C.cast(abi.hip_lib().vimg_hip_build_lbvh, C.c_void_p)

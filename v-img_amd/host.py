@@ -142,6 +142,12 @@ class HostScene:
     def build_bvh(self, kind=abi.BVH_SWEEP):
         self._check(self._lib.vimg_host_build_bvh(self._h, kind))
 
+    def build_bvh_with(self, builder_fn_ptr):
+        """Build the BVH with a caller-supplied builder (a C function pointer with the
+        vimg_bvh_builder_fn signature, e.g. vimg_amd.hip.lbvh_builder())."""
+        self._check(self._lib.vimg_host_build_bvh_with(self._h, builder_fn_ptr))
+        return self
+
     # ---- views ---------------------------------------------------------------------------
     @property
     def view(self):

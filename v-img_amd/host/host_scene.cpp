@@ -606,6 +606,39 @@ int vimg_host_build_bvh(VimgHostScene* s, int bvh_type) {
   return 0;
 }
 
+int vimg_host_build_bvh_with(VimgHostScene* s, vimg_bvh_builder_fn builder) {
+  if (s->prims.empty() || !builder) {
+    host_set_error("build_bvh_with: scene has no surfaces or no builder given");
+    return -1;
+  }
+  std::vector<PrimBounds> bounds;
+  std::vector<V3> centers;
+  prim_bounds(*s, bounds, centers);
+  const uint32_t n = static_cast<uint32_t>(bounds.size());
+  std::vector<float> b6(size_t(n) * 6);
+  for (uint32_t i = 0; i < n; ++i) {
+    b6[i * 6 + 0] = bounds[i].bmin.x, b6[i * 6 + 1] = bounds[i].bmin.y, b6[i * 6 + 2] = bounds[i].bmin.z;
+    b6[i * 6 + 3] = bounds[i].bmax.x, b6[i * 6 + 4] = bounds[i].bmax.y, b6[i * 6 + 5] = bounds[i].bmax.z;
+  }
+  HostBVH bvh;
+  bvh.nodes.resize(size_t(n) * 2 - 1);
+  bvh.bb.resize((bvh.nodes.size() * 2 + 3) * 3);
+  bvh.obj_indices.resize(n);
+  uint32_t num_nodes = 0, depth = 0;
+  if (builder(n, b6.data(), &num_nodes, &depth, bvh.nodes.data(), bvh.bb.data(), bvh.obj_indices.data()) != 0 ||
+      num_nodes == 0 || num_nodes > bvh.nodes.size()) {
+    host_set_error("build_bvh_with: the builder failed");
+    return -1;
+  }
+  bvh.nodes.resize(num_nodes);
+  bvh.bb.resize((size_t(num_nodes) * 2 + 3) * 3);
+  bvh.max_depth = depth;
+  s->bvh = std::move(bvh);
+  s->bvh_built = true;
+  s->refresh_view();
+  return 0;
+}
+
 const VimgScene* vimg_host_scene_view(const VimgHostScene* s) {
   if (!s || !s->bvh_built) {
     host_set_error("scene_view: call vimg_host_build_bvh first");
