@@ -3,15 +3,20 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one full render of the workload (one pass of the hot path over one frame of
-synthetic-free input: the reference's own disney_spheres scene).  N == 1 runs BASELINE.json
-configs[1] exactly: scenes/disney_spheres.json, mis integrator, 512 spp, 1800x800.  N > 1 is
-launched under torch.distributed.run, one rank per GPU: the scene is replicated, 8x8 image tiles are
-dealt to the ranks (tile t -> rank t % N), and the per-rank framebuffer slabs are gathered once
-per step with RCCL (all_gather) and de-interleaved — no collective on the data path.  Scaling is
-WEAK: the image grows with sqrt(N) per axis so that every GPU keeps 1800x800 pixels of work
-(pixels are the unit of parallelism: the reference draws one sequential PCG stream per pixel).
-`--strong` keeps the image at 1800x800 instead (reported in DESIGN.md, not the default).
+A "step" is one full render of the workload: BASELINE.json configs[1] exactly
+(scenes/disney_spheres.json, mis integrator, 512 spp, 1800x800), for every N.
+
+N == 1 renders the frame on one GPU.  N > 1: `python bench.py --gpus N` starts N fresh child
+processes itself (python -m torch.distributed.run, one rank per GPU, before anything in this
+process has touched the GPU) and relays rank 0's JSON line; when it is already running under
+torch.distributed.run (RANK / WORLD_SIZE in the environment) it is a rank.  The scene is
+replicated, 8x8 image tiles are dealt to the ranks (tile t -> rank t % N, the reference's static
+interleave, include/integrators.h:57-65,101), and the per-rank framebuffer slabs are gathered once
+per step with RCCL (one all_gather of equal padded slabs) and de-interleaved — no collective on
+the data path.  Scaling is STRONG: the frame stays 1800x800 at 512 spp, `value` is the rays of
+that frame over the slowest rank's time; rank 0 also times the whole frame alone once (untimed
+extra) so that the line carries t1_ms and efficiency = T1 / (N * T_N).  `--weak` grows the image
+with sqrt(N) per axis instead (every GPU keeps 1800x800 pixels).
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement).
 """
@@ -27,6 +32,8 @@ sys.path.insert(0, ROOT)
 
 SCENE_JSON = os.path.join(ROOT, "tests", "golden", "scenes", "disney_spheres.json")
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2     # wave64 VALU instructions/s (MI355X_MICROARCH.md:54,473)
+VALU_LANE_PEAK = VALU_ISSUE_PEAK * 64     # lane-ops/s
 
 # Algorithmic bytes per event on the reference's own storage layout
 B_ROOT = 8 + 24            # root node + its box, per BVH query
@@ -96,22 +103,69 @@ def cpu_baseline(spp):
                       f"seeds), oracle/liboracle.so on {threads} threads"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no rendezvous in the environment: start N fresh
+    ranks as CHILD processes (never an exec: under rocprofv3 the GPU is initialised before this
+    program starts) and relay rank 0's line.  This process makes no GPU call."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    if proc.returncode != 0 or line is None:
+        raise SystemExit(proc.returncode or 1)
+
+
+def valu_profile(workload):
+    """VALU instruction counts per launch from the committed rocprofv3 PMC pass of this workload
+    (the counts are a property of the deterministic workload; the TIME they are divided by is
+    measured live)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "valu.json")))
+        if t.get("workload") == workload:
+            return t
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=512)
-    ap.add_argument("--strong", action="store_true", help="keep 1800x800 total (strong scaling)")
-    ap.add_argument("--cpu-spp", type=int, default=64, help="samples of the CPU baseline leg (about 15 s on 16 threads)")
+    ap.add_argument("--weak", action="store_true",
+                    help="N>1: grow the image with sqrt(N) per axis (1800x800 pixels per GPU) instead of "
+                         "sharding the fixed 1800x800 frame")
+    ap.add_argument("--strong", action="store_true", help="(default) keep 1800x800 total")
+    ap.add_argument("--cpu-spp", type=int, default=64, help="samples of the CPU baseline legs (about 15 s on 16 threads)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path (host-staged gather), not a measurement")
     ap.add_argument("--verify", action="store_true",
-                    help="N>1: rank 0 also renders the whole frame alone and compares bit for bit")
+                    help="N>1: rank 0 also compares the assembled frame with the single-GPU frame bit for bit")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--res", type=int, nargs=2, default=None, help="rehearsal: another frame size")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
 
     import torch
     import torch.distributed as dist
@@ -120,11 +174,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run "
-                             "(one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
     dev_index = 0 if args.one_device else local_rank
     torch.cuda.set_device(dev_index)
     hip.init(dev_index)
@@ -135,14 +185,15 @@ def main():
             dist.init_process_group("gloo")
 
     n = world
-    if args.strong or n == 1:
-        res = (1800, 800)
+    base = tuple(args.res) if args.res else (1800, 800)
+    if n == 1 or not args.weak:
+        res = base
     else:
-        res = (8 * round(1800 * math.sqrt(n) / 8), 8 * round(800 * math.sqrt(n) / 8))
+        res = (8 * round(base[0] * math.sqrt(n) / 8), 8 * round(base[1] * math.sqrt(n) / 8))
     scene = load_scene(res)
     dev = hip.DeviceScene(scene)
-    kernel_name = dev.kernel
     params = scene.default_params(samples=args.spp, tile_rank=rank, tile_world=n)
+    kernel_name = dev.kernel_for(params)
     W, H = res
     # a dedicated (non-default) stream: the kernels are launched on it and the HIP events that
     # time them are recorded on it
@@ -203,16 +254,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t[0])
     kernel_ms = sum(a.elapsed_time(b) for a, b in events) / args.steps
+    kms = torch.tensor([kernel_ms], dtype=torch.float64, device=red_dev)
+    if n > 1:
+        dist.all_reduce(kms, op=dist.ReduceOp.MAX)
+    kernel_ms_max = float(kms[0])
 
-    if args.verify and n > 1 and rank == 0:
-        alone, _ = dev.render(scene.default_params(samples=args.spp), stream=stream)
+    # untimed extra on rank 0 (strong scaling): the whole frame alone, for T1 and --verify
+    t1_ms = None
+    if n > 1 and rank == 0 and not args.weak:
+        whole = scene.default_params(samples=args.spp)
+        alone = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        dev.render_async(whole, alone, stream=stream)           # warm-up of the whole-frame launch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        dev.render_async(whole, alone, stream=stream)
+        e1.record(stream)
         torch.cuda.synchronize()
-        assert torch.equal(alone, frame), "assembled shards differ from the single-GPU frame"
-        print("verify: assembled frame is bit-identical to the single-GPU frame", file=sys.stderr)
+        t1_ms = e0.elapsed_time(e1)
+        if args.verify:
+            assert torch.equal(alone, frame), "assembled shards differ from the single-GPU frame"
+            print("verify: assembled frame is bit-identical to the single-GPU frame", file=sys.stderr)
+    if n > 1:
+        dist.barrier()
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_rays * args.steps / elapsed / 1e6
         achieved = local_bytes / (kernel_ms * 1e-3) / 1e9
+        workload = f"disney_spheres.json, mis integrator, {args.spp} spp, {W}x{H}"
+        strong = n > 1 and not args.weak
         out = {
             "metric": "Mrays/sec (primary+secondary) at 512 spp",
             "value": round(value, 2),
@@ -222,34 +291,64 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True,
-            "scaling": "strong" if (args.strong and n > 1) else "weak",
+            "scaling": "weak" if (n > 1 and args.weak) else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "reference scene file (scenes/disney_spheres.json), no external assets",
             "config": {
-                "workload": f"disney_spheres.json, mis integrator, {args.spp} spp, {W}x{H}"
-                            + ("" if n == 1 else f" tile-sharded over {n} GPUs "
-                               f"({'fixed image' if args.strong else '1800x800 pixels per GPU'})"),
+                "workload": workload + ("" if n == 1 else f" tile-sharded over {n} GPUs "
+                                        f"({'1800x800 pixels per GPU' if args.weak else 'fixed frame'})"),
                 "integrator": "mis", "spp": args.spp, "resolution": [W, H], "depth": "unbounded",
                 "bvh": "sweep SAH (host)", "sharding": f"tiles%{n}",
             },
             "mpaths_per_s": round(total_paths * args.steps / elapsed / 1e6, 3),
             "rays_per_path": round(total_rays / total_paths, 4),
             "kernel_ms": round(kernel_ms, 3),
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": measured_traffic(f"disney_spheres.json, mis integrator, {args.spp} spp, {W}x{H}")
-                if n == 1 else None,
-                "kernel": kernel_name,
-                "bytes_per_launch": int(local_bytes),
-                "note": "algorithmic bytes on the reference layout (SURVEY.md 8d); the 2 KB scene "
-                        "is LDS/L1 resident, so the kernel is VALU/latency bound, not HBM bound",
-            },
+            "kernel_ms_slowest_rank": round(kernel_ms_max, 3),
         }
+        if strong and t1_ms is not None:
+            out["t1_ms"] = round(t1_ms, 3)
+            out["efficiency"] = round(t1_ms / (n * ms_per_step), 4)
+            out["efficiency_kernels_only"] = round(t1_ms / (n * kernel_ms_max), 4)
+        # The roofline the kernel is under.  The scene of this workload (5.8 KB) is served from LDS,
+        # so the bound is vector issue, not HBM: MI355X_MICROARCH.md:54,473 - a wave64 VALU
+        # instruction takes 2 cycles on a SIMD-32, 1024 SIMDs x 2.4 GHz / 2 = 1.2288e12 wave
+        # instructions/s = 7.86e13 lane-ops/s (the 157.3 TFLOPS FP32 vector figure counts an FMA as 2).
+        vp = valu_profile(workload) if n == 1 else None
+        roof = {
+            "bound": "valu",
+            "kernel": kernel_name,
+            "hbm": {
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "bytes_per_launch": int(local_bytes),
+                "note": "ALGORITHMIC bytes on the reference layout (SURVEY.md 8d); served by LDS/L1 "
+                        "here, not by HBM - see traffic for the bytes that do cross the L2",
+            },
+            "traffic": measured_traffic(workload) if n == 1 else None,
+        }
+        if vp:
+            wave_rate = vp["valu_wave_insts_per_launch"] / (kernel_ms * 1e-3)
+            lane_rate = wave_rate * 64.0 * vp["valu_lane_utilization"]
+            roof.update({
+                "achieved": round(lane_rate / 1e12, 3), "peak": round(VALU_LANE_PEAK / 1e12, 2),
+                "unit": "Tlane-op/s", "frac": round(lane_rate / VALU_LANE_PEAK, 4),
+                "valu": {
+                    "wave_insts_per_launch": vp["valu_wave_insts_per_launch"],
+                    "wave_insts_per_s": round(wave_rate, 0),
+                    "issue_peak_per_s": VALU_ISSUE_PEAK,
+                    "issue_frac": round(wave_rate / VALU_ISSUE_PEAK, 4),
+                    "lane_utilization": vp["valu_lane_utilization"],
+                    "source": vp.get("source", "profiles/valu.json"),
+                },
+            })
+            if roof["traffic"]:
+                roof["measured_hbm_frac"] = round(roof["traffic"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        else:
+            roof.update({"achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "note": "no PMC pass of this exact workload committed: algorithmic-bytes "
+                                 "equivalent against the HBM peak, not measured HBM"})
+        out["roofline"] = roof
         if n == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.cpu_spp)
         print(json.dumps(out), flush=True)

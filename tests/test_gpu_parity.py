@@ -37,14 +37,26 @@ def _ulp_diff(a, b):
 
 
 def _compare_images(gpu, cpu, what, min_exact=0.999, tol=1e-5):
+    """The bar of the module docstring, per pixel: at least `min_exact` of the pixels bit-identical;
+    every other pixel either within tol * (largest radiance of the image) of the oracle's value
+    (last-bit difference carried through), or - a path re-routed by a last-bit difference in a
+    transcendental - still one of the estimator's values: bounded by the image's own range.  The
+    re-routed ones are counted inside the (1 - min_exact) allowance and the image mean is held to
+    tol as well."""
     assert gpu.shape == cpu.shape
     exact = (gpu.view(np.uint32) == cpu.view(np.uint32)).all(axis=-1)
     frac = exact.mean()
-    scale = max(1e-3, float(np.abs(cpu).max()))
-    maxdiff = float(np.abs(gpu.astype(np.float64) - cpu.astype(np.float64)).max())
-    print(f"{what}: bit-identical pixels {frac * 100:.4f} %, max |diff| {maxdiff:.3e}")
+    scale = max(1e-3, float(np.abs(cpu[np.isfinite(cpu)]).max())) if np.isfinite(cpu).any() else 1.0
+    diff = np.abs(gpu.astype(np.float64) - cpu.astype(np.float64))
+    diff[np.isnan(gpu) & np.isnan(cpu)] = 0.0
+    px_diff = diff.max(axis=-1)
+    rerouted = px_diff > tol * scale
+    print(f"{what}: bit-identical pixels {frac * 100:.4f} %, max |diff| {px_diff.max():.3e}, "
+          f"re-routed pixels {int(rerouted.sum())}")
     assert frac >= min_exact, f"{what}: only {frac * 100:.3f} % pixels bit-identical"
-    # pixels that differ must still be the same estimator: bounded by a few path contributions
+    assert rerouted.mean() <= 1.0 - min_exact, f"{what}: {int(rerouted.sum())} pixels beyond {tol} of the range"
+    assert np.all(px_diff[rerouted] <= scale), f"{what}: a differing pixel is outside the image's range"
+    assert np.isfinite(gpu).all() == np.isfinite(cpu).all()
     assert np.abs(gpu.mean() - cpu.mean()) <= tol * scale + 1e-3 * abs(cpu.mean())
 
 
@@ -386,6 +398,28 @@ def test_config2_full_render_against_the_references_own_picture():
     assert np.allclose(ours.mean(axis=(0, 1)), ref.mean(axis=(0, 1)), rtol=0.012)
     assert diff.mean() < 2.0             # of 255 levels
     assert np.percentile(diff, 99) < 8.0
+
+
+def test_cornell_spheres_against_the_references_own_pictures_on_the_gpu():
+    """The reference-held triplet renders/sphere_{mis,mat,ref}.png (cornell_box_spheres, 800x800):
+    the HIP path with the mis integrator against sphere_mis and sphere_ref, with the material
+    integrator against sphere_mat and sphere_ref (what the bounds mean: test_oracle_pins)."""
+    from test_oracle_pins import check_against_sphere_triplet
+    s = scenes.json_scene("cornell_box_spheres.json")
+    d = _dev(s)
+    mis, st = d.render_to_host(s.default_params(samples=100))           # the scene file's own 100 spp
+    assert st.nan_samples == 0
+    check_against_sphere_triplet(mis, "mis", "HIP mis 100 spp")
+    r_mis = check_against_sphere_triplet(mis, "ref", "HIP mis 100 spp")
+    mat, st = d.render_to_host(s.default_params(samples=256, integrator="material"))
+    assert st.nan_samples == 0 and st.shadow_rays == 0
+    # BSDF sampling alone is a high-variance estimator here and clamp + sRGB bias a noisy image dark
+    # by an amount that depends on the sample count (oracle, same scene: 16 spp 0.52, 100 spp 0.90,
+    # 256 spp 1.0 of the converged picture's level; sphere_mat itself sits 6 % under sphere_ref), so
+    # the bounds are wide: same picture, level between the author's two
+    check_against_sphere_triplet(mat, "mat", "HIP material 256 spp", level=(0.98, 1.13), min_corr=0.98, max_mad=8.0)
+    r_mat = check_against_sphere_triplet(mat, "ref", "HIP material 256 spp", level=(0.93, 1.06), min_corr=0.98, max_mad=8.0)
+    assert np.all(r_mat < r_mis + 0.01)
 
 
 @pytest.mark.parametrize("scene_name", ["cornell", "glass_in_box", "feature"])

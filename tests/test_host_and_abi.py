@@ -96,6 +96,167 @@ def test_json_loader_semantics():
     assert np.allclose(verts[:4, 2], -277.5) and np.allclose(np.abs(verts[:4, 0]), 650)
 
 
+def _glm_mat_mul(a, b):
+    """glm mat4 * mat4 on column lists, float32, terms added left to right."""
+    f = np.float32
+    r = []
+    for j in range(4):
+        col = []
+        for i in range(4):
+            acc = f(a[0][i]) * f(b[j][0])
+            for k in (1, 2, 3):
+                acc = f(acc + f(a[k][i]) * f(b[j][k]))
+            col.append(f(acc))
+        r.append(col)
+    return r
+
+
+def _reference_transform(entries):
+    """get_transform of the reference (src/scene_loading/json_scene.cpp:67-121) restated in numpy
+    float32: scale / rotate (quaternion x y z w, glm::toMat4) / translate, each op PRE-multiplying."""
+    f = np.float32
+    ident = lambda: [[f(1 if i == j else 0) for i in range(4)] for j in range(4)]
+    x = ident()
+    for e in entries:
+        m = ident()
+        if "scale" in e:
+            sc = e["scale"] if isinstance(e["scale"], list) else [e["scale"]] * 3
+            for k in range(3):
+                m[k][k] = f(sc[k])
+        elif "rotate" in e:
+            qx, qy, qz, qw = (f(v) for v in e["rotate"])
+            qxx, qyy, qzz = f(qx * qx), f(qy * qy), f(qz * qz)
+            qxz, qxy, qyz = f(qx * qz), f(qx * qy), f(qy * qz)
+            qwx, qwy, qwz = f(qw * qx), f(qw * qy), f(qw * qz)
+            one, two = f(1), f(2)
+            m[0] = [f(one - f(two * f(qyy + qzz))), f(two * f(qxy + qwz)), f(two * f(qxz - qwy)), f(0)]
+            m[1] = [f(two * f(qxy - qwz)), f(one - f(two * f(qxx + qzz))), f(two * f(qyz + qwx)), f(0)]
+            m[2] = [f(two * f(qxz + qwy)), f(two * f(qyz - qwx)), f(one - f(two * f(qxx + qyy))), f(0)]
+        elif "translate" in e:
+            m[3] = [f(e["translate"][0]), f(e["translate"][1]), f(e["translate"][2]), f(1)]
+        x = _glm_mat_mul(m, x)
+    return x
+
+
+def _xform_point(m, p):
+    """xform * vec4(p, 1), then /= w (create_quad_mesh, src/geometry/mesh_loading.cpp:67-77);
+    glm mat * vec association (m0 v0 + m1 v1) + (m2 v2 + m3 v3)."""
+    f = np.float32
+    v = [f(p[0]), f(p[1]), f(p[2]), f(1)]
+    r = [f(f(f(m[0][i] * v[0]) + f(m[1][i] * v[1])) + f(f(m[2][i] * v[2]) + f(m[3][i] * v[3]))) for i in range(4)]
+    return [f(r[0] / r[3]), f(r[1] / r[3]), f(r[2] / r[3])]
+
+
+def test_json_loader_against_a_scene_assembled_by_hand():
+    """Loader-independent check of BASELINE config 2's input: the tables the JSON loader produces for
+    scenes/disney_spheres.json must be, byte for byte, the tables obtained by (a) computing what
+    the reference's loader computes from the same numbers here in numpy float32 - transform order,
+    quad vertices and winding {0,2,1},{2,0,3}, primitive order, lights = the emissive quad's
+    triangles in REVERSE order (add_tri_list_to_scene, mesh_loading.cpp:95-103), one ConstColor
+    texture per Principled material, material parameter defaults (json_scene.cpp:289-314) - and
+    (b) assembling the scene through the HostScene.add_* API from those numbers."""
+    with open(os.path.join(scenes.SCENES, "disney_spheres.json")) as f:
+        d = json.load(f)
+    ref = scenes.json_scene("disney_spheres.json")
+    v = ref.view.contents
+
+    # ---- (a) expected tables, computed here
+    quad_local = [(-1, -1, 0), (-1, 1, 0), (1, 1, 0), (1, -1, 0)]
+    exp_vertices, exp_tri, exp_tri_mesh, exp_prims, exp_lights, exp_spheres = [], [], [], [], [], []
+    mat_index = {m["name"]: i for i, m in enumerate(d["materials"])}
+    mat_type = {m["name"]: m["type"] for m in d["materials"]}
+    n_mesh = 0
+    for surf in d["surfaces"]:
+        if surf["type"] == "quad":
+            m = _reference_transform(surf.get("transform", []))
+            exp_vertices += [_xform_point(m, p) for p in quad_local]
+            first_prim = len(exp_prims)
+            for t in ((0, 2, 1), (2, 0, 3)):
+                exp_tri.append(t)
+                exp_tri_mesh.append(n_mesh)
+                exp_prims.append((abi.PRIM_TRIANGLE, len(exp_tri) - 1))
+            if mat_type[surf["mat_name"]] == "diffuse_light":
+                exp_lights += [(abi.LIGHT_PRIM, first_prim + 1), (abi.LIGHT_PRIM, first_prim)]
+            n_mesh += 1
+        else:
+            exp_spheres.append((surf["center"], surf.get("radius", 1.0), mat_index[surf["mat_name"]]))
+            exp_prims.append((abi.PRIM_SPHERE, len(exp_spheres) - 1))
+    got_vertices = np.ctypeslib.as_array(v.vertices, (v.num_vertices, 3))
+    assert np.array_equal(got_vertices.view(np.uint32), np.asarray(exp_vertices, np.float32).view(np.uint32))
+    assert np.ctypeslib.as_array(v.tri_indices, (v.num_tris, 3)).tolist() == [list(t) for t in exp_tri]
+    assert np.ctypeslib.as_array(v.tri_mesh, (v.num_tris,)).tolist() == exp_tri_mesh
+    assert [(v.prims[i].type, v.prims[i].index) for i in range(v.num_prims)] == exp_prims
+    assert [(v.lights[i].type, v.lights[i].prim) for i in range(v.num_lights)] == exp_lights
+    assert v.num_spheres == len(exp_spheres)
+    for i, (c, r, m) in enumerate(exp_spheres):
+        sp = v.spheres[i]
+        assert (list(sp.center), sp.radius, sp.material) == ([np.float32(x) for x in c], np.float32(r), m)
+    uv = np.ctypeslib.as_array(v.uvs, (v.num_uvs, 2))
+    assert uv.tolist() == [[0, 0], [0, 1], [1, 1], [1, 0]] * n_mesh
+    assert v.background.type == abi.BG_CONST and list(v.background.col) == [0, 0, 0]      # quirk Q3
+    assert (v.camera.res_x, v.camera.res_y, v.camera.vfov_deg, v.camera.aperture_radius) == (1800, 800, float(d["camera"]["vfov"]), 0.0)
+
+    # ---- (b) the same scene through the add_* API (meshes from the vertices computed above)
+    s = host.HostScene()
+    cam = d["camera"]
+    s.set_camera(cam["transform"]["from"], cam["transform"]["at"], cam["transform"]["up"], cam["vfov"],
+                 cam["resolution"])
+    s.set_render_defaults(d["integrator"]["type"], d["sampler"]["samples"], d["sampler"]["depth"])
+    for m in d["materials"]:
+        if m["type"] == "lambertian":
+            s.add_material("lambertian", tex=s.add_texture_const(m["albedo"]))
+        elif m["type"] == "diffuse_light":
+            s.add_material("diffuse_light", emit=m["albedo"])
+        else:
+            s.add_material("principled", tex=s.add_texture_const(m["base_color"]),
+                           roughness=m.get("roughness", 0.5), anisotropic=m.get("anisotropic", 0.0),
+                           eta=m.get("eta", 1.5), subsurface=m.get("subsurface", 0.0),
+                           metallic=m.get("metallic", 0.0), spec_trans=m.get("spec_trans", 0.0),
+                           specular=m.get("specular", 0.5), spec_tint=m.get("spec_tint", 0.0),
+                           sheen=m.get("sheen", 0.0), sheen_tint=m.get("sheen_tint", 0.5),
+                           clearcoat=m.get("clearcoat", 0.0), clearcoat_gloss=m.get("clearcoat_gloss", 1.0))
+    k = 0
+    for surf in d["surfaces"]:
+        if surf["type"] == "quad":
+            s.add_mesh(np.asarray(exp_vertices[4 * k:4 * k + 4], np.float32), [[0, 2, 1], [2, 0, 3]],
+                       mat_index[surf["mat_name"]], uv_sets=[[[0, 0], [0, 1], [1, 1], [1, 0]]], color_uv=0)
+            k += 1
+        else:
+            s.add_sphere(surf["center"], surf.get("radius", 1.0), mat_index[surf["mat_name"]])
+    s.set_background_const((0, 0, 0), add_to_lights=False)
+    s.build_bvh(abi.BVH_SWEEP)
+    w = s.view.contents
+
+    def table(ptr, n, ctype):
+        return C.string_at(ptr, n * C.sizeof(ctype)) if n else b""
+    for name, cnt, ctype in (("prims", "num_prims", abi.Prim), ("meshes", "num_meshes", abi.Mesh),
+                             ("spheres", "num_spheres", abi.Sphere),
+                             ("textures", "num_textures", abi.Texture), ("lights", "num_lights", abi.Light)):
+        assert getattr(v, cnt) == getattr(w, cnt), name
+        assert table(getattr(v, name), getattr(v, cnt), ctype) == table(getattr(w, name), getattr(w, cnt), ctype), name
+    # materials: the fields their type reads (the loader leaves the others zero, the API at its defaults)
+    used = {abi.MAT_LAMBERTIAN: ("tex",), abi.MAT_DIFFUSE_LIGHT: ("emit",),
+            abi.MAT_PRINCIPLED: ("tex", "mr_tex", "normal_map", "metallic_factor", "roughness_factor",
+                                 "specular_transmission", "subsurface", "specular", "specular_tint",
+                                 "anisotropic", "sheen", "sheen_tint", "clearcoat", "clearcoat_gloss", "eta")}
+    assert v.num_materials == w.num_materials == len(d["materials"])
+    for i in range(v.num_materials):
+        a, b = v.materials[i], w.materials[i]
+        assert a.type == b.type
+        for fld in used[a.type]:
+            fa, fb = getattr(a, fld), getattr(b, fld)
+            assert (list(fa) == list(fb)) if fld == "emit" else (fa == fb), (i, fld)
+    assert v.num_vertices == w.num_vertices and v.num_tris == w.num_tris and v.num_uvs == w.num_uvs
+    assert C.string_at(v.vertices, v.num_vertices * 12) == C.string_at(w.vertices, w.num_vertices * 12)
+    assert C.string_at(v.tri_indices, v.num_tris * 12) == C.string_at(w.tri_indices, w.num_tris * 12)
+    assert C.string_at(v.uvs, v.num_uvs * 8) == C.string_at(w.uvs, w.num_uvs * 8)
+    assert bytes(v.camera) == bytes(w.camera) and bytes(v.background) == bytes(w.background)
+    for a, b in zip(ref.bvh_arrays(), s.bvh_arrays()):
+        assert np.array_equal(a, b)
+    pr, ps = ref.default_params(), s.default_params()
+    assert (pr.integrator, pr.samples, pr.depth) == (ps.integrator, ps.samples, ps.depth) == (abi.INTEGRATOR_MIS, 512, 0xFFFFFFFF)
+
+
 def test_json_loader_errors_and_defaults():
     with pytest.raises(host.HostError):
         vimg_amd.HostScene.from_json("/nonexistent/scene.json")
@@ -125,10 +286,14 @@ def test_json_loader_errors_and_defaults():
 
 
 # ------------------------------------------------------------------------------- BVH builders
-def test_json_mesh_surface_loads_obj_positions_and_fans_polygons(tmp_path):
+def test_json_mesh_surface_loads_obj_positions_and_splits_quads_like_tinyobj(tmp_path):
     """"type": "mesh" (reference src/scene_loading/json_scene.cpp:366-385 + load_from_obj,
-    src/geometry/mesh_loading.cpp:21-65): positions only, path relative to the scene file, every
-    face a fan, 1-based / negative indices, v/vt/vn tokens; the transform is applied to positions."""
+    src/geometry/mesh_loading.cpp:21-65): positions only, path relative to the scene file,
+    1-based / negative indices, v/vt/vn tokens; the transform is applied to positions.  Quads are
+    split as the reference's bundled tinyobjloader splits them (include/tiny_obj_loader.h:1488-1583):
+    along the shorter diagonal of the UNTRANSFORMED positions, [0,1,2],[0,2,3] only when
+    |v2-v0|^2 < |v3-v1|^2 and [0,1,3],[1,2,3] otherwise - so every square (a tie) takes the second
+    form; polygons with more than four vertices are refused."""
     (tmp_path / "assets").mkdir()
     (tmp_path / "scenes").mkdir()
     obj = """# unit cube
@@ -149,6 +314,11 @@ f 2//1 3//1 7//1 6//1
 f 3 4 8 7
 f 4 1 5
 f 4 5 8
+v 0 0 2
+v 3 0 2
+v 1 1 2
+v 0 1 2
+f 9 10 11 12
 """
     (tmp_path / "assets" / "cube.obj").write_text(obj)
     scene = {
@@ -166,18 +336,24 @@ f 4 5 8
     path.write_text(json.dumps(scene))
     s = host.HostScene.from_json(str(path))
     v = s.view.contents
-    assert v.num_meshes == 2 and v.num_prims == 12 + 2
+    assert v.num_meshes == 2 and v.num_prims == 14 + 2
     m = v.meshes[0]
-    assert (m.num_vertices, m.has_normals, m.num_uv_sets, m.color_tex_uv) == (8, 0, 0, abi.NO_UV)
+    assert (m.num_vertices, m.has_normals, m.num_uv_sets, m.color_tex_uv) == (12, 0, 0, abi.NO_UV)
     verts = np.ctypeslib.as_array(v.vertices, (v.num_vertices, 3))[:8]
     want = np.array([[-.5, -.5, -.5], [.5, -.5, -.5], [.5, .5, -.5], [-.5, .5, -.5], [-.5, -.5, .5],
                      [.5, -.5, .5], [.5, .5, .5], [-.5, .5, .5]], dtype=np.float32)
     want = (want + np.float32([0, 0.5, 0])) * np.float32([1, 9, 4])     # translate, then scale
     assert np.array_equal(verts, want)
-    tri = np.ctypeslib.as_array(v.tri_indices, (v.num_tris, 3))[:12]
-    assert tri.tolist() == [[0, 3, 2], [0, 2, 1], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4],
-                            [1, 2, 6], [1, 6, 5], [2, 3, 7], [2, 7, 6], [3, 0, 4], [3, 4, 7]]
-    # errors: missing file, face before its vertices
+    tri = np.ctypeslib.as_array(v.tri_indices, (v.num_tris, 3))[:14]
+    assert tri.tolist() == [[0, 3, 1], [3, 2, 1], [4, 5, 7], [5, 6, 7], [0, 1, 4], [1, 5, 4],   # squares: ties
+                            [1, 2, 5], [2, 6, 5], [2, 3, 6], [3, 7, 6], [3, 0, 4], [3, 4, 7],
+                            [8, 9, 10], [8, 10, 11]]               # |v2-v0|^2 = 2 < |v3-v1|^2 = 10
+    # errors: polygon with more than four vertices, missing file, face before its vertices
+    (tmp_path / "scenes" / "penta.obj").write_text("v 0 0 0\nv 1 0 0\nv 2 1 0\nv 1 2 0\nv 0 1 0\nf 1 2 3 4 5\n")
+    scene["surfaces"][0]["filename"] = "penta.obj"
+    path.write_text(json.dumps(scene))
+    with pytest.raises(host.HostError, match="more than 4 vertices"):
+        host.HostScene.from_json(str(path))
     scene["surfaces"][0]["filename"] = "nope.obj"
     path.write_text(json.dumps(scene))
     with pytest.raises(host.HostError, match="cannot open"):

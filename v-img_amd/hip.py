@@ -26,6 +26,38 @@ def _check(rc):
     return rc
 
 
+_side = None
+
+
+class _Ordered:
+    """The stream a launch with torch tensors goes to.  `stream=None` means torch's CURRENT stream,
+    never the library's private one (which is non-blocking and would not be ordered against the
+    fill of `out` or against torch consumers of the result).  The legacy null stream has no
+    handle the library could tell from "no stream given", so work for it goes to a side stream
+    that waits for the null stream before the launch and that the null stream waits for after."""
+
+    def __init__(self, stream):
+        import torch
+        global _side
+        self.cur = stream if stream is not None else torch.cuda.current_stream()
+        self.side = None
+        if self.cur.cuda_stream == 0:
+            if _side is None:
+                _side = torch.cuda.Stream()
+            self.side = _side
+
+    def __enter__(self):
+        if self.side is not None:
+            self.side.wait_stream(self.cur)
+            return C.c_void_p(self.side.cuda_stream)
+        return C.c_void_p(self.cur.cuda_stream)
+
+    def __exit__(self, *exc):
+        if self.side is not None:
+            self.cur.wait_stream(self.side)
+        return False
+
+
 def device_count():
     return _check(_lib().vimg_hip_device_count())
 
@@ -52,6 +84,15 @@ class DeviceScene:
     def kernel(self):
         return self._lib.vimg_hip_scene_kernel(self._h).decode()
 
+    def kernel_for(self, params):
+        """Name of the kernel a launch with these parameters gets (the scheduler is chosen per launch)."""
+        fn = getattr(self._lib, "vimg_hip_launch_kernel", None)
+        if fn is None:
+            return self.kernel
+        fn.restype = C.c_char_p
+        fn.argtypes = [C.c_void_p, C.c_void_p]
+        return fn(self._h, C.byref(params)).decode()
+
     def shard_pixels(self, params):
         return _check(self._lib.vimg_hip_shard_pixels(self._h, C.byref(params)))
 
@@ -69,15 +110,15 @@ class DeviceScene:
                 out = torch.zeros((self.shard_pixels(params), 3), dtype=torch.float32,
                                   device="cuda")
         st = abi.RenderStats()
-        sp = C.c_void_p(stream.cuda_stream) if stream is not None else None
-        _check(self._lib.vimg_hip_render(self._h, C.byref(params), C.c_void_p(out.data_ptr()), sp,
-                                         C.byref(st) if stats else None))
+        with _Ordered(stream) as sp:
+            _check(self._lib.vimg_hip_render(self._h, C.byref(params), C.c_void_p(out.data_ptr()), sp,
+                                             C.byref(st) if stats else None))
         return (out, st) if stats else out
 
     def render_async(self, params, out, stream=None):
-        sp = C.c_void_p(stream.cuda_stream) if stream is not None else None
-        _check(self._lib.vimg_hip_render_async(self._h, C.byref(params),
-                                               C.c_void_p(out.data_ptr()), sp))
+        with _Ordered(stream) as sp:
+            _check(self._lib.vimg_hip_render_async(self._h, C.byref(params),
+                                                   C.c_void_p(out.data_ptr()), sp))
 
     def render_to_host(self, params, stats=True):
         """Render and copy the framebuffer to a numpy array [H, W, 3] (no torch needed)."""
@@ -99,9 +140,9 @@ class DeviceScene:
             out = torch.empty((n, 3), dtype=torch.float32, device="cuda")
             if params.tile_world == 1:
                 out = out.view(h, w, 3)
-        sp = C.c_void_p(stream.cuda_stream) if stream is not None else None
-        _check(self._lib.vimg_hip_render_heatmap(self._h, C.byref(params), factor,
-                                                 C.c_void_p(out.data_ptr()), sp))
+        with _Ordered(stream) as sp:
+            _check(self._lib.vimg_hip_render_heatmap(self._h, C.byref(params), factor,
+                                                     C.c_void_p(out.data_ptr()), sp))
         return out
 
     def trace_pixel(self, params, x, y):
@@ -115,10 +156,10 @@ class DeviceScene:
         w, h = self.resolution
         if out is None:
             out = torch.empty((h, w, 3), dtype=torch.float32, device="cuda")
-        sp = C.c_void_p(stream.cuda_stream) if stream is not None else None
-        _check(self._lib.vimg_hip_assemble_shards(self._h, world, shard_stride_pixels,
-                                                  C.c_void_p(gathered.data_ptr()),
-                                                  C.c_void_p(out.data_ptr()), sp))
+        with _Ordered(stream) as sp:
+            _check(self._lib.vimg_hip_assemble_shards(self._h, world, shard_stride_pixels,
+                                                      C.c_void_p(gathered.data_ptr()),
+                                                      C.c_void_p(out.data_ptr()), sp))
         return out
 
     def time_renders(self, params, out, steps):
@@ -159,9 +200,9 @@ def post_rgb8(image, tonemapper=1, stream=None):
     import torch
     h, w = image.shape[0], image.shape[1]
     out = torch.empty((h, w, 3), dtype=torch.uint8, device=image.device)
-    sp = C.c_void_p(stream.cuda_stream) if stream is not None else None
-    _check(_lib().vimg_hip_post_rgb8(C.c_void_p(image.data_ptr()), w, h, tonemapper,
-                                     C.c_void_p(out.data_ptr()), sp))
+    with _Ordered(stream) as sp:
+        _check(_lib().vimg_hip_post_rgb8(C.c_void_p(image.data_ptr()), w, h, tonemapper,
+                                         C.c_void_p(out.data_ptr()), sp))
     return out
 
 

@@ -152,18 +152,21 @@ int add_quad_impl(VimgHostScene& s, const M4& xform, uint32_t material) {
 
 // load_from_obj, reference src/geometry/mesh_loading.cpp:21-65: positions only ("v" lines,
 // transformed by the surface transform with the perspective divide) and the triangles of every
-// face ("f" lines: vertex index before the first '/', 1-based or negative = relative to the end;
-// polygons are split into a fan, which is what tinyobjloader's default triangulation does with
-// the convex polygons it is fed here).  Normals and texture coordinates of the file are ignored,
-// as in the reference; the mesh goes through the legacy Mesh ctor with no uv set
-// (include/geometry/mesh.h:33-41).
+// face ("f" lines: vertex index before the first '/', 1-based or negative = relative to the end).
+// Triangulation is tinyobjloader's (reference include/tiny_obj_loader.h:1488-1583, real_t = float):
+// a quad is split along its SHORTER diagonal, measured on the untransformed file positions -
+// [0,1,2],[0,2,3] only when |v2-v0|^2 < |v3-v1|^2, otherwise (ties included, i.e. every square and
+// rectangle) [0,1,3],[1,2,3].  Polygons with more than four vertices go through an ear-clipping
+// loop there; they are refused here with an explicit error rather than triangulated differently.
+// Normals and texture coordinates of the file are ignored, as in the reference; the mesh goes
+// through the legacy Mesh ctor with no uv set (include/geometry/mesh.h:33-41).
 int add_obj_mesh(VimgHostScene& s, const std::string& path, const M4& xform, uint32_t material) {
   std::ifstream f(path);
   if (!f) {
     g_err = "Tinyobj failed to load the mesh: cannot open " + path;
     return -1;
   }
-  std::vector<float> verts;
+  std::vector<float> verts, raw;   // transformed positions; positions as the file has them
   std::vector<uint32_t> idx;
   std::vector<long> face;
   std::string line;
@@ -176,6 +179,7 @@ int add_obj_mesh(VimgHostScene& s, const std::string& path, const M4& xform, uin
       ls >> p.x >> p.y >> p.z;
       V3 q = hm::xform_point(xform, p);
       verts.insert(verts.end(), {q.x, q.y, q.z});
+      raw.insert(raw.end(), {p.x, p.y, p.z});
     } else if (tag == "f") {
       face.clear();
       std::string tok;
@@ -189,9 +193,33 @@ int add_obj_mesh(VimgHostScene& s, const std::string& path, const M4& xform, uin
         }
         face.push_back(vi);
       }
-      for (size_t k = 2; k < face.size(); ++k)
-        idx.insert(idx.end(), {static_cast<uint32_t>(face[0]), static_cast<uint32_t>(face[k - 1]),
-                               static_cast<uint32_t>(face[k])});
+      auto tri = [&](int a, int b, int c) {
+        idx.insert(idx.end(), {static_cast<uint32_t>(face[a]), static_cast<uint32_t>(face[b]),
+                               static_cast<uint32_t>(face[c])});
+      };
+      if (face.size() < 3) continue;   // "Degenerated face": skipped by tinyobj too
+      if (face.size() == 3) {
+        tri(0, 1, 2);
+      } else if (face.size() == 4) {
+        const float* v0 = &raw[size_t(face[0]) * 3];
+        const float* v1 = &raw[size_t(face[1]) * 3];
+        const float* v2 = &raw[size_t(face[2]) * 3];
+        const float* v3 = &raw[size_t(face[3]) * 3];
+        const float e02x = v2[0] - v0[0], e02y = v2[1] - v0[1], e02z = v2[2] - v0[2];
+        const float e13x = v3[0] - v1[0], e13y = v3[1] - v1[1], e13z = v3[2] - v1[2];
+        const float sqr02 = e02x * e02x + e02y * e02y + e02z * e02z;
+        const float sqr13 = e13x * e13x + e13y * e13y + e13z * e13z;
+        if (sqr02 < sqr13) {
+          tri(0, 1, 2);
+          tri(0, 2, 3);
+        } else {
+          tri(0, 1, 3);
+          tri(1, 2, 3);
+        }
+      } else {
+        g_err = "obj face with more than 4 vertices (tinyobj ear-clips these; not reproduced): " + path;
+        return -1;
+      }
     }
   }
   if (idx.empty()) {
