@@ -36,11 +36,48 @@ int vimg_hip_init(int device_ordinal);
 /* Number of visible HIP devices, or a negative error code. */
 int vimg_hip_device_count(void);
 
+/* How a scene's frames are scheduled on the GPU.  Every field: VIMG_OPT_AUTO (-1) = the library's
+ * policy (stated per field); the three schedulers execute the same per-path arithmetic and give
+ * the same bits.  The reference has no counterpart (its scheduler is the tile loop of
+ * include/integrators.h:57-101); these are the knobs of OUR replacement of that loop, at the
+ * boundary instead of in the environment.  (For tools/ only, VIMG_HIP_* environment variables
+ * still override single fields at upload: scheduler VIMG_HIP_SCHED=lane|pool|stage, the others
+ * as named in vimg_hip.hip:options_from_env.) */
+#define VIMG_OPT_AUTO (-1)
+enum {
+  VIMG_SCHED_LANE = 1,   /* render_kernel: one path per lane, persistent waves */
+  VIMG_SCHED_POOL = 2,   /* render_pool_kernel: ~240 path slots per wave in LDS, walk + vertex stages in one wave */
+  VIMG_SCHED_STAGE = 3,  /* render_stage_kernel: path state in HBM slots, stages coupled by global queues, 4 waves/SIMD */
+  VIMG_SCHED_POOL4 = 4   /* render_pool4_kernel: the pooled scheduler with the vertex stage as calls, 4 waves/SIMD */
+};
+typedef struct VimgHipOptions {
+  uint32_t struct_size;       /* sizeof(VimgHipOptions): lets the library accept older callers */
+  int32_t scheduler;          /* AUTO: POOL4; LANE for launches with fewer pixels than 1.5 x the pooled slots in flight */
+  int32_t waves_per_simd;     /* register budget: LANE / POOL 2 or 3 (AUTO: LANE 3 for scenes > 32 MiB else 2; POOL 2), POOL4 3 or 4 (AUTO 3) */
+  int32_t lds_budget_kb;      /* LDS per workgroup for BVH top + stacks.  AUTO: 40 (LANE), stacks + 4.5 (POOL / STAGE) */
+  int32_t pool_slots;         /* POOL: path slots per wave.  AUTO: what the CU's LDS holds (<= 256) */
+  int32_t pool_segments;      /* POOL: segments a pixel's samples are cut into.  AUTO: ~56 / pool generations, <= 16 */
+  int32_t pool_refill;        /* POOL / STAGE walk: finished rays that trigger a refill pass.  AUTO 16 */
+  int32_t pool_vbatch;        /* POOL: queued slots of one class that start a vertex batch.  AUTO 64 */
+  int32_t pool_classes;       /* POOL: vertex queues by material, 1..3.  AUTO 3 */
+  int32_t pool_starve;        /* POOL: idle walk lanes that force a partial vertex batch.  AUTO 24 */
+  int32_t pool_boxmin;        /* POOL / STAGE, deep trees: leave the box loop below this many descending lanes.  AUTO 16 */
+  int32_t lds_leaf;           /* POOL / STAGE: 0 = never copy the leaf records to LDS.  AUTO: when they fit 4 KiB */
+  int32_t stage_slots;        /* STAGE: path slots in flight.  AUTO: 2 x resident lanes, <= pixels of the launch */
+  int32_t stage_seg_len;      /* STAGE: samples a pixel stays bound to a slot.  AUTO 4 */
+  int32_t stage_wchunk;       /* STAGE: slot ids a walking wave stages in LDS, 128..256.  AUTO 128 */
+  int32_t stage_walk_quota;   /* STAGE: rays a wave walks before it looks at the queues again.  AUTO 2048 */
+} VimgHipOptions;
+/* Fills every field with VIMG_OPT_AUTO (and struct_size). */
+void vimg_hip_options_default(VimgHipOptions* opts);
+
 /* Validates the tables of `scene` (index ranges, BVH child ranges, stack bound), bakes them
  * into the device layout described in DESIGN.md and copies them to HBM.  The host arrays may
  * be freed afterwards.  Replaces nothing in the reference (its scene is already in RAM); it is
- * the "load once" half of the seam so that the timed render starts with inputs resident. */
+ * the "load once" half of the seam so that the timed render starts with inputs resident.
+ * `opts` may be NULL (= all AUTO); vimg_hip_scene_upload(scene, out) is that case. */
 int vimg_hip_scene_upload(const VimgScene* scene, VimgDeviceScene** out);
+int vimg_hip_scene_upload_opts(const VimgScene* scene, const VimgHipOptions* opts, VimgDeviceScene** out);
 int vimg_hip_scene_free(VimgDeviceScene* scene);
 
 /* Number of float triples a shard's compact framebuffer holds
@@ -143,9 +180,11 @@ int vimg_hip_rgb8_to_normal(const uint8_t* rgb8, uint64_t n_pixels, float scale,
 int vimg_hip_build_lbvh(uint32_t n, const float* bounds6, uint32_t* num_nodes, uint32_t* max_depth,
                         VimgBVHNode* nodes, float* bb, uint32_t* obj_indices);
 
-/* Name of the render kernel this scene is launched with (the upload picks the build: textured or
- * not, register budget, lane-bound or pooled scheduler) - what a rocprofv3 kernel trace will show. */
+/* Name of the render kernel a whole frame of this scene is launched with (textured or not,
+ * register budget, scheduler) - what a rocprofv3 kernel trace will show - and the one a launch
+ * with these parameters gets (the scheduler is chosen per launch: thin shards may differ). */
 const char* vimg_hip_scene_kernel(const VimgDeviceScene* scene);
+const char* vimg_hip_launch_kernel(const VimgDeviceScene* scene, const VimgRenderParams* params);
 
 const char* vimg_hip_last_error(void);
 

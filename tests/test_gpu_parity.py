@@ -84,11 +84,37 @@ def test_image_matches_oracle_json_scenes(name, res, spp, depth):
     assert gst.nan_samples == cst.nan_samples
 
 
+def _dev_opts(scene, **opts):
+    from vimg_amd import hip
+    return hip.DeviceScene(scene, **opts)
+
+
+# scheduler configurations (VimgHipOptions): every one must give the lane-bound kernel's bits
+SCHEDULES = {
+    "lane": dict(scheduler="lane"),
+    "pool": dict(scheduler="pool"),
+    # the pooled kernel with every pixel's samples cut into 5 segments that travel through per-pixel
+    # records in global memory; at test sizes far more slots are in flight than there are pixels,
+    # so slots constantly draw segments whose predecessor is still running (the waiting path)
+    "pool/5": dict(scheduler="pool", pool_segments=5),
+    "pool/64": dict(scheduler="pool", pool_segments=64),
+    # the pooled scheduler with its vertex stage as calls, four waves per SIMD
+    "pool4": dict(scheduler="pool4"),
+    "pool4/5": dict(scheduler="pool4", pool_segments=5),
+    # the staged kernel: as many slots as pixels (policy), then far fewer slots than pixels so that
+    # pixels queue in the ready FIFO, one-sample and whole-pixel segments, the smallest walk chunk
+    "stage": dict(scheduler="stage"),
+    "stage/few": dict(scheduler="stage", stage_slots=300, stage_seg_len=1),
+    "stage/whole": dict(scheduler="stage", stage_slots=1000, stage_seg_len=1 << 20, stage_walk_quota=128),
+}
+
+
 @pytest.mark.parametrize("scene_name", ["disney_spheres.json", "glass_in_box.json", "feature"])
-def test_both_render_kernels_give_the_same_bits(scene_name, monkeypatch):
-    """render_kernel (one path per lane) and render_pool_kernel (paths pooled in LDS) are two
-    schedules of the same per-path arithmetic: identical images, identical event counts, whichever
-    the upload policy would pick for the scene; trace_pixel and shards included."""
+def test_all_schedulers_give_the_same_bits(scene_name):
+    """render_kernel (one path per lane), render_pool_kernel (paths pooled in LDS) and
+    render_stage_kernel (path state in HBM, stages coupled by queues) are three schedules of the
+    same per-path arithmetic: identical images, identical event counts, whichever the policy would
+    pick for the scene; trace_pixel and repeated launches on the same scratch included."""
     if scene_name == "feature":
         s = scenes.feature_scene(res=(72, 48), envmap=True, lens=True)
         p = s.default_params(samples=6, depth=7)
@@ -96,42 +122,34 @@ def test_both_render_kernels_give_the_same_bits(scene_name, monkeypatch):
         s = scenes.json_scene(scene_name, res=(136, 72))
         p = s.default_params(samples=12)
     out = {}
-    # "1/5": the pooled kernel with every pixel's samples cut into 5 segments that travel through
-    # per-pixel records in global memory; at this size far more slots are in flight than there
-    # are pixels, so slots constantly draw segments whose predecessor is still running (the
-    # waiting path), often inside the same wave
-    for pool in ("0", "1", "1/5", "1/64"):
-        monkeypatch.setenv("VIMG_HIP_POOL", pool[0])
-        if "/" in pool:
-            monkeypatch.setenv("VIMG_HIP_POOL_SEGMENTS", pool.split("/")[1])
-        else:
-            monkeypatch.delenv("VIMG_HIP_POOL_SEGMENTS", raising=False)
-        d = _dev(s)
+    for name, opts in SCHEDULES.items():
+        d = _dev_opts(s, **opts)
+        assert d.kernel.startswith({"lane": "render_kernel", "pool": "render_pool_kernel", "pool4": "render_pool4_kernel",
+                                    "stage": "render_stage_kernel"}[opts["scheduler"]]), (name, d.kernel)
         img, st = d.render_to_host(p)
-        again, _ = d.render_to_host(p)            # a second launch on the same records (new epoch)
-        assert np.array_equal(img.view(np.uint32), again.view(np.uint32)), pool
+        again, _ = d.render_to_host(p)            # a second launch on the same records
+        assert np.array_equal(img.view(np.uint32), again.view(np.uint32)), name
         px = d.trace_pixel(p, 17, 23)
-        out[pool] = (img, st, px)
-    a, b = out["0"], out["1"]
-    for other in ("1", "1/5", "1/64"):
-        o = out[other]
+        out[name] = (img, st, px)
+    a = out["lane"]
+    for other, o in out.items():
         assert np.array_equal(a[0].view(np.uint32), o[0].view(np.uint32)), other
         assert np.array_equal(np.asarray(a[2]).view(np.uint32), np.asarray(o[2]).view(np.uint32)), other
         assert a[1].as_dict() == o[1].as_dict(), other
     cpu, cst, _ = O.render(s, p)
-    _compare_images(b[0], cpu, scene_name + " (pooled kernel)")
-    assert b[1].paths == cst.paths
+    _compare_images(out["stage"][0], cpu, scene_name + " (staged kernel)")
+    assert out["stage"][1].paths == cst.paths
 
 
 @pytest.mark.parametrize("case", ["config3", "config4", "config5", "big_mesh", "cornell material",
                                   "feature material", "glass s_normal", "disney g_normal",
                                   "sphere lights", "const background light"])
-def test_pooled_scheduler_on_every_feature(case, monkeypatch):
-    """Frames of test size go to the lane-bound kernel by policy, so the pooled scheduler is forced
-    here on every feature the path has - image textures with mips, normal and RG maps, env-map and
-    constant-background lights, sphere lights, thin lens, deep trees (the DEEP build), the material
-    and normal integrators - with and without segments, and must give the lane-bound kernel's bits
-    and event counts."""
+def test_pooled_and_staged_schedulers_on_every_feature(case):
+    """Frames of test size go to the lane-bound kernel by policy, so the other two schedulers are
+    asked for by name here on every feature the path has - image textures with mips, normal and RG
+    maps, env-map and constant-background lights, sphere lights, thin lens, deep trees (the DEEP
+    builds), the material and normal integrators - and must give the lane-bound kernel's bits and
+    event counts."""
     mk = {
         "config3": lambda: (scenes.config3_scene(res=(96, 72), env=(128, 64)), dict(samples=8, depth=12)),
         "config4": lambda: (scenes.config4_scene(res=(96, 54), n_lat=48, env=(128, 64)), dict(samples=8, depth=12)),
@@ -147,16 +165,12 @@ def test_pooled_scheduler_on_every_feature(case, monkeypatch):
     }[case]
     s, kw = mk()
     p = s.default_params(**kw)
-    monkeypatch.setenv("VIMG_HIP_POOL", "0")
-    lane, st_lane = _dev(s).render_to_host(p)
-    for seg in ("1", "3"):
-        monkeypatch.setenv("VIMG_HIP_POOL", "1")
-        monkeypatch.setenv("VIMG_HIP_POOL_SEGMENTS", seg)
-        d = _dev(s)
-        assert d.kernel.startswith("render_pool_kernel")
-        pool, st_pool = d.render_to_host(p)
-        assert np.array_equal(pool.view(np.uint32), lane.view(np.uint32)), (case, seg)
-        assert st_pool.as_dict() == st_lane.as_dict(), (case, seg)
+    lane, st_lane = _dev_opts(s, scheduler="lane").render_to_host(p)
+    for name in ("pool", "pool/5", "pool4", "pool4/5", "stage", "stage/few"):
+        d = _dev_opts(s, **SCHEDULES[name])
+        img, st = d.render_to_host(p)
+        assert np.array_equal(img.view(np.uint32), lane.view(np.uint32)), (case, name, d.kernel)
+        assert st.as_dict() == st_lane.as_dict(), (case, name)
 
 
 @pytest.mark.parametrize("integrator", ["s_normal", "g_normal"])
@@ -307,29 +321,31 @@ def test_full_size_properties_disney_spheres():
     assert np.allclose(d.trace_pixel(p, 900, 400), ref, rtol=1e-5, atol=1e-6)
 
 
-def test_full_size_schedulers_and_segments_agree(monkeypatch):
-    """BASELINE config 2 at full resolution: the upload policy launches the pooled kernel with the
-    samples of a pixel cut into segments (items = 3.5 pool generations), a thin shard of the same
-    frame goes to the lane-bound kernel; both give the bits of the lane-bound kernel on the whole
-    frame.  Size-independent property: the image does not depend on scheduler, segment count or
+def test_full_size_schedulers_and_segments_agree():
+    """BASELINE config 2 at full resolution: the policy launches the pooled scheduler in its
+    four-waves-per-SIMD build with the samples of a pixel cut into segments; the first pooled
+    kernel with its own segment policy and with seven segments, the staged kernel, the lane-bound
+    kernel and a thin shard all give the same bits.  Size-independent property: the image does not depend on scheduler, segment count or
     shard count."""
     s = scenes.json_scene("disney_spheres.json")
     p = s.default_params(samples=16)
     d = _dev(s)
-    assert d.kernel.startswith("render_pool_kernel")
+    assert d.kernel.startswith("render_pool4_kernel")
     auto, st_auto = d.render_to_host(p)
-    monkeypatch.setenv("VIMG_HIP_POOL_SEGMENTS", "7")      # 16 samples in segments of 3 (+1)
-    seg, st_seg = _dev(s).render_to_host(p)
-    monkeypatch.delenv("VIMG_HIP_POOL_SEGMENTS")
-    monkeypatch.setenv("VIMG_HIP_POOL", "0")
-    lane_dev = _dev(s)
+    stage, st_stage = _dev_opts(s, scheduler="stage").render_to_host(p)
+    pool_dev = _dev_opts(s, scheduler="pool")
+    assert pool_dev.kernel.startswith("render_pool_kernel")
+    pool, st_pool = pool_dev.render_to_host(p)
+    seg, st_seg = _dev_opts(s, scheduler="pool", pool_segments=7).render_to_host(p)   # 16 samples in segments of 3 (+1)
+    lane_dev = _dev_opts(s, scheduler="lane")
     assert lane_dev.kernel.startswith("render_kernel")
     lane, st_lane = lane_dev.render_to_host(p)
     assert np.array_equal(auto.view(np.uint32), lane.view(np.uint32))
+    assert np.array_equal(stage.view(np.uint32), lane.view(np.uint32))
+    assert np.array_equal(pool.view(np.uint32), lane.view(np.uint32))
     assert np.array_equal(seg.view(np.uint32), lane.view(np.uint32))
-    assert st_auto.as_dict() == st_lane.as_dict() == st_seg.as_dict()
-    monkeypatch.delenv("VIMG_HIP_POOL")
-    # an eighth of the frame (what one GPU of eight renders under --strong): too small for the pools
+    assert st_auto.as_dict() == st_lane.as_dict() == st_seg.as_dict() == st_pool.as_dict() == st_stage.as_dict()
+    # an eighth of the frame (what one GPU of eight renders of the fixed frame)
     import torch
     from vimg_amd import dist as vdist
     p8 = s.default_params(samples=16, tile_rank=3, tile_world=8)

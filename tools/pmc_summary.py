@@ -12,7 +12,7 @@ agg = collections.OrderedDict()
 meta = {}
 for f in sorted(glob.glob(f"{out_dir}/pmc*/*/*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if "render_kernel" in r["Kernel_Name"] or "render_pool_kernel" in r["Kernel_Name"]:
+        if any(n in r["Kernel_Name"] for n in ("render_kernel", "render_pool_kernel", "render_pool4_kernel", "render_stage_kernel")):
             agg[r["Counter_Name"]] = agg.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
             meta = {k: r[k] for k in ["Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size",
                                       "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count"]}

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Frame time of one scheduler configuration on BASELINE config 2 (or a stand-in scene).
+Usage (GPU box): python tools/sched_bench.py <scheduler> [spp] [scene] [key=value ...]
+  scheduler: lane | pool | stage | auto;  scene: disney (default) | config3 | config4 | config5
+  key=value: VimgHipOptions fields (stage_slots=..., stage_seg_len=...), tile_world=N, tile_rank=R, res=WxH"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import scenes
+from vimg_amd import hip
+sched = sys.argv[1]
+pos = [a for a in sys.argv[2:] if "=" not in a]
+kv = dict(a.split("=") for a in sys.argv[2:] if "=" in a)
+spp = int(pos[0]) if pos else 64
+which = pos[1] if len(pos) > 1 else "disney"
+tw, tr = int(kv.pop("tile_world", 1)), int(kv.pop("tile_rank", 0))
+res = tuple(int(v) for v in kv.pop("res").split("x")) if "res" in kv else None
+steps = int(kv.pop("steps", 2))
+opts = {k: int(v) for k, v in kv.items()}
+if sched != "auto":
+    opts["scheduler"] = sched
+hip.init(0)
+if which == "disney":
+    s = scenes.json_scene("disney_spheres.json", res=res)
+else:
+    s = {"config3": scenes.config3_scene, "config4": scenes.config4_scene, "config5": lambda: scenes.config5_scene(n=700)}[which]()
+d = hip.DeviceScene(s, **opts)
+p = s.default_params(samples=spp, tile_rank=tr, tile_world=tw)
+w, h = s.resolution
+n_out = w * h if tw == 1 else d.shard_pixels(p)
+out = torch.empty((n_out, 3), dtype=torch.float32, device="cuda")
+_, st = d.render(p, out=out)
+ms = d.time_renders(p, out, steps)
+sec = float(ms.min()) * 1e-3
+print(json.dumps({"scheduler": sched, "kernel": d.kernel_for(p), "scene": which, "res": [w, h], "spp": spp, "tile_world": tw,
+                  "opts": opts, "ms": [round(float(m), 2) for m in ms], "mrays_per_s": round(st.rays / sec / 1e6, 1),
+                  "rays": st.rays}), flush=True)

@@ -123,6 +123,33 @@ class RenderStats(C.Structure):
         return int(self.closest_rays) + int(self.shadow_rays)
 
 
+OPT_AUTO = -1
+SCHED_LANE, SCHED_POOL, SCHED_STAGE, SCHED_POOL4 = 1, 2, 3, 4
+SCHEDULERS = {"lane": SCHED_LANE, "pool": SCHED_POOL, "stage": SCHED_STAGE, "pool4": SCHED_POOL4}
+
+
+class HipOptions(C.Structure):
+    """VimgHipOptions (include/vimg_hip.h): every field -1 = the library's policy."""
+    _fields_ = [("struct_size", u32), ("scheduler", i32), ("waves_per_simd", i32),
+                ("lds_budget_kb", i32), ("pool_slots", i32), ("pool_segments", i32),
+                ("pool_refill", i32), ("pool_vbatch", i32), ("pool_classes", i32),
+                ("pool_starve", i32), ("pool_boxmin", i32), ("lds_leaf", i32),
+                ("stage_slots", i32), ("stage_seg_len", i32), ("stage_wchunk", i32),
+                ("stage_walk_quota", i32)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        self.struct_size = C.sizeof(HipOptions)
+        for name, _ in self._fields_[1:]:
+            setattr(self, name, OPT_AUTO)
+        for k, v in kw.items():
+            if k == "scheduler" and isinstance(v, str):
+                v = SCHEDULERS[v]
+            if k not in dict(self._fields_):
+                raise TypeError(f"unknown option {k}")
+            setattr(self, k, v)
+
+
 PScene = C.POINTER(Scene)
 PParams = C.POINTER(RenderParams)
 PStats = C.POINTER(RenderStats)
@@ -166,7 +193,9 @@ HOST_SYMBOLS = {
 HIP_SYMBOLS = {
     "vimg_hip_init": (C.c_int, [C.c_int]),
     "vimg_hip_device_count": (C.c_int, []),
+    "vimg_hip_options_default": (None, [C.POINTER(HipOptions)]),
     "vimg_hip_scene_upload": (C.c_int, [PScene, C.POINTER(C.c_void_p)]),
+    "vimg_hip_scene_upload_opts": (C.c_int, [PScene, C.POINTER(HipOptions), C.POINTER(C.c_void_p)]),
     "vimg_hip_scene_free": (C.c_int, [C.c_void_p]),
     "vimg_hip_shard_pixels": (i64, [C.c_void_p, PParams]),
     "vimg_hip_render": (C.c_int, [C.c_void_p, PParams, C.c_void_p, C.c_void_p, PStats]),
@@ -188,6 +217,7 @@ HIP_SYMBOLS = {
                                      C.POINTER(u32)]),
     "vimg_hip_scene_bytes": (i64, [C.c_void_p]),
     "vimg_hip_scene_kernel": (C.c_char_p, [C.c_void_p]),
+    "vimg_hip_launch_kernel": (C.c_char_p, [C.c_void_p, PParams]),
     "vimg_hip_last_error": (C.c_char_p, []),
 }
 

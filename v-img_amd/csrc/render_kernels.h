@@ -1524,6 +1524,23 @@ VD float geometric_term(f3 look_from, f3 point_on_surface, f3 surface_normal) {
 
 // ================================================================================ LDS set-up
 VD uint32_t lds_node_bytes(uint32_t n) { return n * (3 * 16 + 8); }
+// where the node planes and this lane's stack live (pointer arithmetic only)
+VD Lds lds_layout(const RenderArgs& A, VIMG_LDS unsigned char* lds_raw) {
+  const uint32_t n = A.lds_nodes;
+  VIMG_LDS v4f* na = reinterpret_cast<VIMG_LDS v4f*>(lds_raw);
+  VIMG_LDS v4f* nb = na + n;
+  VIMG_LDS v4f* nc = nb + n;
+  VIMG_LDS v2u* nm = reinterpret_cast<VIMG_LDS v2u*>(nc + n);
+  // stacks start at the next 256-byte boundary: [wave][entry][lane]
+  uint32_t stack_off = (lds_node_bytes(n) + 255u) & ~255u;
+  VIMG_LDS uint32_t* stacks = reinterpret_cast<VIMG_LDS uint32_t*>(lds_raw + stack_off);
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  Lds L;
+  L.na = na, L.nb = nb, L.nc = nc, L.nm = nm;
+  L.stack = stacks + size_t(wave) * A.stack_entries * 64 + lane;
+  L.n_nodes = n;
+  return L;
+}
 VD Lds stage_lds(const DScene& g, const RenderArgs& A, VIMG_LDS unsigned char* lds_raw) {
   const uint32_t n = A.lds_nodes;
   VIMG_LDS v4f* na = reinterpret_cast<VIMG_LDS v4f*>(lds_raw);
@@ -1538,15 +1555,7 @@ VD Lds stage_lds(const DScene& g, const RenderArgs& A, VIMG_LDS unsigned char* l
     nm[i] = v2u{src->left_ref, src->right_ref};
   }
   __syncthreads();
-  // stacks start at the next 256-byte boundary: [wave][entry][lane]
-  uint32_t stack_off = (lds_node_bytes(n) + 255u) & ~255u;
-  VIMG_LDS uint32_t* stacks = reinterpret_cast<VIMG_LDS uint32_t*>(lds_raw + stack_off);
-  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  Lds L;
-  L.na = na, L.nb = nb, L.nc = nc, L.nm = nm;
-  L.stack = stacks + size_t(wave) * A.stack_entries * 64 + lane;
-  L.n_nodes = n;
-  return L;
+  return lds_layout(A, lds_raw);
 }
 
 // ================================================================================ render kernel

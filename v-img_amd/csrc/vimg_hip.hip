@@ -18,6 +18,8 @@
 #include "pre_kernels.h"
 #include "render_kernels.h"
 #include "render_pool_kernel.h"
+#include "render_stage_kernel.h"
+#include "render_pool4_kernel.h"
 #include "heatmap_kernel.h"
 
 using namespace vimg;
@@ -51,10 +53,9 @@ struct VimgDeviceScene {
   std::vector<void*> allocs;
   size_t total_bytes = 0;
   bool textured = false;       // needs the TEX=true kernels (cones, image textures, env map)
-  int waves_per_simd = 2;      // which register-budget build of the kernel to launch
-  bool pooled = false;         // render_pool_kernel (LDS path pool) instead of render_kernel
-  bool wps_forced = false;     // register budget asked for by name (VIMG_HIP_WAVES_PER_SIMD)
-  bool pool_forced = false;    // ... asked for by name (VIMG_HIP_POOL=1): also for frames too small to fill the pools
+  VimgHipOptions opt{};        // the caller's options (VIMG_OPT_AUTO where the policy decides)
+  int waves_per_simd = 2;      // LANE register budget by policy (scene size)
+  bool too_wide = false;       // resolution beyond the 16-bit pixel coordinates of the slot records
   uint32_t num_cus = 0;
   uint32_t num_leaf_prims = 0;   // records in d.leaf_prims (= primitives of the scene)
   // scratch owned by the scene: stats, work counter, host-render framebuffer
@@ -67,6 +68,17 @@ struct VimgDeviceScene {
   size_t pool_state_bytes = 0;
   uint32_t pool_epoch = 0;       // bumped per launch: tags of earlier launches never match
   size_t frame_floats = 0;
+  // staged kernel: control block, queue rings, ready-pixel ring, per-pixel records, slot records
+  void* d_stage_ctl = nullptr;
+  void* d_stage_kargs = nullptr;   // StageKArgs block of the launch in flight
+  void* d_stage_rings = nullptr;
+  size_t stage_rings_bytes = 0;
+  void* d_stage_pix_ring = nullptr;
+  size_t stage_pix_ring_bytes = 0;
+  void* d_stage_pix_state = nullptr;
+  size_t stage_pix_state_bytes = 0;
+  void* d_stage_slots = nullptr;
+  size_t stage_slots_bytes = 0;
 };
 
 namespace {
@@ -209,6 +221,26 @@ int validate(const VimgScene* sc) {
   return VIMG_OK;
 }
 
+// tools/ only: VIMG_HIP_* environment variables override single option fields at upload (sweeps
+// and profiles without a rebuild of the caller); tests and the product pass VimgHipOptions
+void options_from_env(VimgHipOptions* o) {
+  if (const char* e = getenv("VIMG_HIP_SCHED")) {
+    const std::string v(e);
+    o->scheduler = v == "lane" ? VIMG_SCHED_LANE : v == "pool" ? VIMG_SCHED_POOL : v == "stage" ? VIMG_SCHED_STAGE
+                 : v == "pool4" ? VIMG_SCHED_POOL4 : atoi(e);
+  }
+  struct { const char* name; int32_t* field; } vars[] = {
+      {"VIMG_HIP_WAVES_PER_SIMD", &o->waves_per_simd}, {"VIMG_HIP_LDS_BUDGET_KB", &o->lds_budget_kb},
+      {"VIMG_HIP_POOL_SLOTS", &o->pool_slots},         {"VIMG_HIP_POOL_SEGMENTS", &o->pool_segments},
+      {"VIMG_HIP_POOL_REFILL", &o->pool_refill},       {"VIMG_HIP_POOL_VBATCH", &o->pool_vbatch},
+      {"VIMG_HIP_POOL_CLASSES", &o->pool_classes},     {"VIMG_HIP_POOL_STARVE", &o->pool_starve},
+      {"VIMG_HIP_POOL_BOXMIN", &o->pool_boxmin},       {"VIMG_HIP_LDS_LEAF", &o->lds_leaf},
+      {"VIMG_HIP_STAGE_SLOTS", &o->stage_slots},       {"VIMG_HIP_STAGE_SEG_LEN", &o->stage_seg_len},
+      {"VIMG_HIP_STAGE_WCHUNK", &o->stage_wchunk},     {"VIMG_HIP_STAGE_WALK_QUOTA", &o->stage_walk_quota}};
+  for (auto& v : vars)
+    if (const char* e = getenv(v.name)) *v.field = atoi(e);
+}
+
 uint32_t tiles_of(int n) { return (static_cast<uint32_t>(n) + 7u) / 8u; }
 
 uint32_t local_tiles(const VimgDeviceScene* s, const VimgRenderParams* p) {
@@ -233,13 +265,18 @@ int check_params(const VimgDeviceScene* s, const VimgRenderParams* p) {
 
 struct LaunchCfg {
   RenderArgs args;
+  StageArgs stage;
   uint32_t grid, lds_bytes;
+  int sched;     // VIMG_SCHED_* of this launch
   bool pooled;   // render_pool_kernel for this launch
   int wps;       // register-budget build (waves per SIMD of __launch_bounds__)
-  bool deep;     // pooled kernel: build whose box loop yields to waiting leaves (tree beyond the LDS node cache)
+  bool deep;     // pooled / staged kernel: build whose box loop yields to waiting leaves (tree beyond the LDS node cache)
 };
 
 using RenderKernel = void (*)(const DScene, const RenderArgs, float*, DeviceStats*, unsigned int*);
+using StageKernel = void (*)(const StageKArgs*);
+using Pool4Kernel = void (*)(const Pool4KArgs*);
+Pool4Kernel pick_pool4_kernel(const VimgDeviceScene* s, bool deep, int wps);
 RenderKernel pick_kernel(const VimgDeviceScene* s, bool pooled, int wps, bool deep) {
   if (pooled) {
     if (deep) {
@@ -252,17 +289,66 @@ RenderKernel pick_kernel(const VimgDeviceScene* s, bool pooled, int wps, bool de
   if (s->textured) return wps >= 3 ? render_kernel<true, 3> : render_kernel<true, 2>;
   return wps >= 3 ? render_kernel<false, 3> : render_kernel<false, 2>;
 }
+StageKernel pick_stage_kernel(const VimgDeviceScene* s, bool deep) {
+  if (s->textured) return deep ? render_stage_kernel<true, true> : render_stage_kernel<true, false>;
+  return deep ? render_stage_kernel<false, true> : render_stage_kernel<false, false>;
+}
+Pool4Kernel pick_pool4_kernel(const VimgDeviceScene* s, bool deep, int wps) {
+  if (wps <= 3) {
+    if (s->textured) return deep ? render_pool4_kernel<true, true, 3> : render_pool4_kernel<true, false, 3>;
+    return deep ? render_pool4_kernel<false, true, 3> : render_pool4_kernel<false, false, 3>;
+  }
+  if (s->textured) return deep ? render_pool4_kernel<true, true, 4> : render_pool4_kernel<true, false, 4>;
+  return deep ? render_pool4_kernel<false, true, 4> : render_pool4_kernel<false, false, 4>;
+}
+const void* kernel_of(const VimgDeviceScene* s, const LaunchCfg& c) {
+  if (c.sched == VIMG_SCHED_STAGE) return reinterpret_cast<const void*>(pick_stage_kernel(s, c.deep));
+  if (c.sched == VIMG_SCHED_POOL4) return reinterpret_cast<const void*>(pick_pool4_kernel(s, c.deep, c.wps));
+  return reinterpret_cast<const void*>(pick_kernel(s, c.pooled, c.wps, c.deep));
+}
 
+uint32_t opt_or(int32_t v, uint32_t dflt) { return v == VIMG_OPT_AUTO ? dflt : static_cast<uint32_t>(v); }
+uint32_t ceil_pow2(uint64_t v) {
+  uint32_t p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+uint32_t log2_of(uint32_t pow2) {
+  uint32_t k = 0;
+  while ((1u << k) < pow2) ++k;
+  return k;
+}
+
+// The policy of one launch.  `sched_override`: 0 = by options / policy, else the scheduler to build
+// the configuration for (the fall-back from a scheduler that cannot take this launch).
 LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int sx, int sy,
-                      bool for_render = true, bool allow_pool = true) {
+                      bool for_render = true, int sched_override = 0) {
   LaunchCfg c{};
-  c.pooled = s->pooled && for_render && allow_pool;
+  const VimgHipOptions& o = s->opt;
+  const uint64_t items = (sx >= 0) ? 1 : uint64_t(local_tiles(s, p)) * 64u;
+  // ---- which scheduler.  Policy (AUTO): the pooled scheduler in its four-waves-per-SIMD build;
+  // launches too small to fill its pools - fewer pixels than 1.5 x the slots in flight: test images,
+  // trace_pixel, very thin shards - go to the lane-bound kernel (decided below, once the pool size
+  // is known).  The staged kernel (global queues) runs when asked for by name.
+  int sched = sched_override ? sched_override : (o.scheduler == VIMG_OPT_AUTO ? 0 : o.scheduler);
+  const bool by_policy = (sched == 0);
+  if (!for_render) sched = VIMG_SCHED_LANE;   // probes and the heatmap only need the LDS layout
+  if (sched == 0) sched = VIMG_SCHED_POOL4;
+  if (s->too_wide && sched != VIMG_SCHED_LANE) sched = VIMG_SCHED_LANE;        // slots pack pixel coordinates in 16 bits
+  if (sched == VIMG_SCHED_STAGE && items > (1ull << 26)) sched = VIMG_SCHED_POOL4;   // 32-bit byte offsets of the pixel records
+  c.sched = sched;
+  c.pooled = (sched == VIMG_SCHED_POOL || sched == VIMG_SCHED_POOL4);
   // register budget: the lane-bound kernel wants 3 waves per SIMD on scenes beyond the on-chip
   // caches (latency-bound) and 2 on small ones (VALU-bound, fewest spills); the pooled kernel
   // hides latency with its slots and always takes the 256-register build (config 4/5: 2 waves
-  // 1.02 / 1.70 Grays/s, 3 waves 0.66 / 0.91)
+  // 1.02 / 1.70 Grays/s, 3 waves 0.66 / 0.91); the staged kernel has one build (128 registers)
   c.wps = c.pooled ? 2 : s->waves_per_simd;
-  if (s->wps_forced) c.wps = s->waves_per_simd;
+  if (o.waves_per_simd != VIMG_OPT_AUTO) c.wps = o.waves_per_simd >= 3 ? 3 : 2;
+  if (sched == VIMG_SCHED_STAGE) c.wps = 4;
+  // pool4: three waves per SIMD by policy (config 2: 12.2 Grays/s at three, 11.3 at four; the stand-ins
+  // of configs 3 / 4 / 5: 6.6 / 1.56 / 2.62 against 6.1 / 1.15 / 1.52 - a wave's LDS share, i.e. its
+  // pool, shrinks faster than the fourth wave pays, most of all under the deep trees' stacks)
+  if (sched == VIMG_SCHED_POOL4) c.wps = (o.waves_per_simd == 4) ? 4 : 3;
   RenderArgs& a = c.args;
   a.integrator = p->integrator;
   a.samples = p->samples;
@@ -279,54 +365,75 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   // LDS budget per 256-thread workgroup: stacks first, then as much of the top of the tree as
   // fits in 40 KiB total (keeps >= 4 workgroups per CU inside the 160 KiB)
   const uint32_t stack_bytes = 4u * a.stack_entries * 64u * 4u;
-  // (the pooled kernel spends LDS on path slots instead: it keeps the first six levels of the tree,
-  // 4 KiB - config 5: 40 KiB budget 1.69, 28 KiB 1.78 Grays/s)
-  uint32_t budget = c.pooled ? std::min(40u * 1024u, stack_bytes + 4608u) : 40u * 1024u;
-  if (const char* e = getenv("VIMG_HIP_LDS_BUDGET_KB")) budget = uint32_t(std::max(1, atoi(e))) * 1024u;
+  // (the pooled and staged kernels spend LDS on path slots / queue chunks instead: they keep the
+  // first six levels of the tree, 4 KiB - config 5: 40 KiB budget 1.69, 28 KiB 1.78 Grays/s)
+  uint32_t budget = (sched != VIMG_SCHED_LANE) ? std::min(40u * 1024u, stack_bytes + 4608u) : 40u * 1024u;
+  if (o.lds_budget_kb != VIMG_OPT_AUTO) budget = uint32_t(std::max(1, o.lds_budget_kb)) * 1024u;
   uint32_t nodes = 0;
   if (stack_bytes + 512 < budget) nodes = (budget - stack_bytes - 256) / 56u;
   a.lds_nodes = std::min(nodes, s->d.num_nodes);
   c.lds_bytes = ((a.lds_nodes * 56u + 255u) & ~255u) + stack_bytes;
   a.pool_slots = 0;
-  a.pool_refill = 16;
-  a.pool_vbatch = 64;
-  a.pool_classes = 3;
-  a.pool_starve = 24;
+  a.pool_refill = std::max(1u, opt_or(o.pool_refill, 16u));
+  a.pool_vbatch = std::min(64u, std::max(1u, opt_or(o.pool_vbatch, 64u)));
+  a.pool_classes = std::min(3u, std::max(1u, opt_or(o.pool_classes, 3u)));
+  a.pool_starve = std::min(64u, std::max(1u, opt_or(o.pool_starve, 24u)));
   // config 4 / 5 stand-ins: never 1.02 / 1.74, 8 lanes 1.19 / 2.10, 16: 1.18 / 2.13, 24: 1.20 / 2.13,
   // 40: 1.15 / 1.93 Grays/s
-  a.pool_boxmin = 16;
-  if (const char* e = getenv("VIMG_HIP_POOL_BOXMIN")) a.pool_boxmin = uint32_t(std::min(64, std::max(0, atoi(e))));
-  c.deep = c.pooled && a.lds_nodes < s->d.num_nodes;   // the other build reads every node from LDS
-  if (const char* e = getenv("VIMG_HIP_POOL_STARVE")) a.pool_starve = uint32_t(std::min(64, std::max(1, atoi(e))));
-  if (const char* e = getenv("VIMG_HIP_POOL_VBATCH")) a.pool_vbatch = uint32_t(std::min(64, std::max(1, atoi(e))));
-  if (const char* e = getenv("VIMG_HIP_POOL_CLASSES")) a.pool_classes = uint32_t(std::min(3, std::max(1, atoi(e))));
+  a.pool_boxmin = std::min(64u, opt_or(o.pool_boxmin, 16u));
+  c.deep = (sched != VIMG_SCHED_LANE) && a.lds_nodes < s->d.num_nodes;   // the other build reads every node from LDS
+  // small scenes: all leaf records in LDS too (they cost a few slots, the walk gains more)
+  uint32_t leaf_bytes = 0;
+  a.lds_leaf = 0;
+  if (sched != VIMG_SCHED_LANE && s->num_leaf_prims * 48u <= 4096u && o.lds_leaf != 0) {
+    a.lds_leaf = s->num_leaf_prims;
+    leaf_bytes = a.lds_leaf * 48u;
+  }
   if (c.pooled) {
     // the pool takes what is left of this workgroup's share of the CU's 160 KiB
     const uint32_t share = (160u * 1024u) / uint32_t(c.wps) - 1024u;
-    const uint32_t per_slot = POOL_LDS_BYTES * 4u;   // LDS bytes per slot, all four waves
-    // small scenes: all leaf records in LDS too (they cost a few slots, the walk gains more)
-    uint32_t leaf_bytes = 0;
-    a.lds_leaf = 0;
-    if (s->num_leaf_prims * 48u <= 4096u && !getenv("VIMG_HIP_NO_LDS_LEAF")) {
-      a.lds_leaf = s->num_leaf_prims;
-      leaf_bytes = a.lds_leaf * 48u;
-    }
+    const uint32_t slot_bytes = (sched == VIMG_SCHED_POOL4) ? P4_LDS_BYTES : POOL_LDS_BYTES;
+    const uint32_t per_slot = slot_bytes * 4u;   // LDS bytes per slot, all four waves
+    if (sched == VIMG_SCHED_POOL4) c.lds_bytes += 4u * uint32_t(sizeof(Pool4Wave) + sizeof(Pool4Diag));
     uint32_t slots = share > c.lds_bytes + leaf_bytes + 64u ? (share - c.lds_bytes - leaf_bytes - 64u) / per_slot : 0;
     slots = std::min(slots, 256u);
-    if (const char* e = getenv("VIMG_HIP_POOL_SLOTS")) slots = std::min(slots, uint32_t(atoi(e)));
-    if (const char* e = getenv("VIMG_HIP_POOL_REFILL")) a.pool_refill = uint32_t(std::max(1, atoi(e)));
+    if (o.pool_slots != VIMG_OPT_AUTO) slots = std::min(slots, uint32_t(std::max(0, o.pool_slots)));
     a.pool_slots = std::max(slots, 8u);
-    c.lds_bytes += 4u * ((POOL_LDS_BYTES * a.pool_slots + 15u) & ~15u) + leaf_bytes;
+    if (sched == VIMG_SCHED_POOL4) a.pool_slots &= ~1u;   // even: every wave's cold region starts on a 64-byte line
+    c.lds_bytes += 4u * ((slot_bytes * a.pool_slots + 15u) & ~15u) + leaf_bytes;
+  }
+  StageArgs& g = c.stage;
+  if (sched == VIMG_SCHED_STAGE) {
+    g.wchunk = std::min(STAGE_WCHUNK_MAX, std::max(128u, opt_or(o.stage_wchunk, 128u)));
+    g.walk_quota = std::max(g.wchunk, opt_or(o.stage_walk_quota, 2048u));
+    g.seg_len = std::max(1u, opt_or(o.stage_seg_len, 4u));
+    c.lds_bytes += 4u * (5u * g.wchunk * 4u + 256u) + leaf_bytes;
   }
   // persistent grid: as many 4-wave workgroups as the kernel's registers and LDS let a CU hold
   // (asked of the runtime), never more than the work
   int per_cu = 0;
-  hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_kernel(s, c.pooled, c.wps, c.deep), 256, c.lds_bytes);
+  hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel_of(s, c), 256, c.lds_bytes);
   if (oe != hipSuccess || per_cu < 1) per_cu = 1;
-  const uint64_t items = (sx >= 0) ? 1 : uint64_t(a.num_local_tiles) * 64u;
   const uint64_t need_blocks = (items + 255) / 256;
   c.grid = static_cast<uint32_t>(
       std::max<uint64_t>(1, std::min<uint64_t>(need_blocks, uint64_t(s->num_cus) * per_cu)));
+  if (sched == VIMG_SCHED_STAGE) {
+    // slots in flight: twice the resident lanes (every stage then finds full batches queued while
+    // as many paths are being worked on), never more than the pixels of the launch, which are the
+    // unit of parallelism (one sequential RNG stream per pixel, include/integrators.h:116-127)
+    const uint64_t lanes = uint64_t(c.grid) * 256u;
+    uint64_t n = opt_or(o.stage_slots, static_cast<uint32_t>(std::min<uint64_t>(lanes * 2u, STAGE_MAX_SLOTS)));
+    n = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(n, items), STAGE_MAX_SLOTS));
+    g.n_slots = static_cast<uint32_t>(n);
+    g.ring_cap = std::max(64u, ceil_pow2(n));
+    g.ring_shift = log2_of(g.ring_cap);
+    g.pix_cap = std::max(64u, ceil_pow2(items));
+    g.pix_shift = log2_of(g.pix_cap);
+    g.rings_bytes = GQ_COUNT * GQ_SHARDS * g.ring_cap * 4u;
+    g.pix_ring_bytes = g.pix_cap * 4u;
+    g.pix_state_bytes = static_cast<uint32_t>(items * 32u);
+    g.slots_bytes = g.n_slots * GR_BYTES;
+  }
   // pooled kernel: split every pixel's samples into segments handed out as separate work items
   // when the image is large against the slots in flight (then the previous segment of a pixel
   // has long been published when its next one is drawn); small images keep one segment
@@ -335,9 +442,9 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   if (a.pool_slots && sx < 0) {
     const uint64_t in_flight = uint64_t(c.grid) * 4u * a.pool_slots;
     // A frame with fewer pixels than 1.5 x the slots in flight does not fill the pools (904x400:
-    // pooled 3.1, lane-bound 4.5 Grays/s): such launches - small images, thin shards of a strong-
-    // scaling run - go to the lane-bound kernel, unless the pooled one was asked for by name.
-    if (!s->pool_forced && items * 2u < in_flight * 3u) return make_launch(s, p, sx, sy, for_render, false);
+    // pooled 3.1, lane-bound 4.5 Grays/s): such launches go to the lane-bound kernel, unless the
+    // pooled scheduler was asked for by name.
+    if (by_policy && !sched_override && items * 2u < in_flight * 3u) return make_launch(s, p, sx, sy, for_render, VIMG_SCHED_LANE);
     // Segments: the tail of a frame is one segment long, and every hand-over costs a little
     // (config 2, 3.5 pool generations per frame: 1 segment 6.8, 4: 7.5, 8: 7.6, 16-32: 7.6 Grays/s;
     // 3600x1600, 14 generations: 1 segment 7.9, 4: 7.7) - about 56 segments per generation count,
@@ -346,7 +453,7 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
     uint32_t k = gens >= 10.0 ? 1u : uint32_t(std::min(16.0, std::max(1.0, std::floor(56.0 / gens + 0.5))));
     k = std::min<uint32_t>(k, std::max<uint32_t>(p->samples / 4u, 1u));
     if (items * 2u < in_flight * 3u) k = 1u;
-    if (const char* e = getenv("VIMG_HIP_POOL_SEGMENTS")) k = uint32_t(std::max(1, atoi(e)));
+    if (o.pool_segments != VIMG_OPT_AUTO) k = uint32_t(std::max(1, o.pool_segments));
     k = std::min<uint32_t>(k, 4096u);
     while (k > 1u && items * k >= 0xfff00000ull) --k;   // (segment, pixel) items must fit the 32-bit counter
     const uint32_t len = std::max<uint32_t>((p->samples + k - 1) / k, 1u);
@@ -361,7 +468,8 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
 int ensure_pool(VimgDeviceScene* s, LaunchCfg& c) {
   c.args.pool_cold = nullptr;
   if (!c.pooled || c.args.pool_slots == 0) return VIMG_OK;
-  const size_t ncold = s->textured ? SC_COUNT : SC_COUNT - 1u;
+  const size_t ncold = (c.sched == VIMG_SCHED_POOL4) ? pool4_cold_records(s->textured)
+                                                      : (s->textured ? SC_COUNT : SC_COUNT - 1u);
   const size_t need = size_t(c.grid) * 4u * ncold * c.args.pool_slots * 16u;
   if (need > s->pool_cold_bytes) {
     if (s->d_pool_cold) HIP_TRY(hipFree(s->d_pool_cold));
@@ -396,31 +504,97 @@ int ensure_pool(VimgDeviceScene* s, LaunchCfg& c) {
   return VIMG_OK;
 }
 
-int launch_render(VimgDeviceScene* s, const VimgRenderParams* p, float* d_out, hipStream_t st,
-                  bool full_stats, bool want_stats, int sx, int sy) {
+// The staged kernel keeps all path state in global memory, owned by the scene and grown on demand:
+// control block, queue rings, ready-pixel ring, per-pixel records, slot records (config 2 on 256
+// CUs: 0.01 + 42 + 8 + 46 + 50 MB).  Counters, rings and the ready-pixel ring are cleared per launch.
+int grow(void** p, size_t* have, size_t need) {
+  if (need <= *have) return VIMG_OK;
+  if (*p) HIP_TRY(hipFree(*p));
+  *p = nullptr;
+  *have = 0;
+  HIP_TRY(hipMalloc(p, need));
+  *have = need;
+  return VIMG_OK;
+}
+int ensure_stage(VimgDeviceScene* s, LaunchCfg& c, hipStream_t st) {
+  if (c.sched != VIMG_SCHED_STAGE) return VIMG_OK;
+  StageArgs& g = c.stage;
+  if (!s->d_stage_ctl) HIP_TRY(hipMalloc(&s->d_stage_ctl, sizeof(StageCtl)));
+  if (int rc = grow(&s->d_stage_rings, &s->stage_rings_bytes, g.rings_bytes)) return rc;
+  if (int rc = grow(&s->d_stage_pix_ring, &s->stage_pix_ring_bytes, g.pix_ring_bytes)) return rc;
+  if (int rc = grow(&s->d_stage_pix_state, &s->stage_pix_state_bytes, g.pix_state_bytes)) return rc;
+  if (int rc = grow(&s->d_stage_slots, &s->stage_slots_bytes, g.slots_bytes)) return rc;
+  g.ctl = (VIMG_GLOBAL StageCtl*)s->d_stage_ctl;
+  g.rings = (VIMG_GLOBAL uint32_t*)s->d_stage_rings;
+  g.pix_ring = (VIMG_GLOBAL uint32_t*)s->d_stage_pix_ring;
+  g.pix_state = (VIMG_GLOBAL v4u*)s->d_stage_pix_state;
+  g.slots = (VIMG_GLOBAL v4u*)s->d_stage_slots;
+  HIP_TRY(hipMemsetAsync(s->d_stage_ctl, 0, sizeof(StageCtl), st));
+  HIP_TRY(hipMemsetAsync(s->d_stage_rings, 0, g.rings_bytes, st));
+  HIP_TRY(hipMemsetAsync(s->d_stage_pix_ring, 0, g.pix_ring_bytes, st));
+  // pixels nobody has started: all of them but one per slot (the slots start "fresh")
+  const uint64_t items = (c.args.single_x >= 0) ? 1 : uint64_t(c.args.num_local_tiles) * 64u;
+  const uint32_t surplus = static_cast<uint32_t>(items - g.n_slots);
+  StageCtl* ctl = static_cast<StageCtl*>(s->d_stage_ctl);
+  HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&ctl->surplus.v), static_cast<int>(surplus), 1, st));
+  return VIMG_OK;
+}
+
+// Enqueues one render on `st` (counter / queue resets, then the kernel); ev0 / ev1, when given, are
+// recorded right before and right after the kernel itself.
+int enqueue_render(VimgDeviceScene* s, const VimgRenderParams* p, float* d_out, hipStream_t st,
+                   bool full_stats, bool want_stats, int sx, int sy, hipEvent_t ev0 = nullptr,
+                   hipEvent_t ev1 = nullptr) {
   LaunchCfg c = make_launch(s, p, sx, sy);
   if (int rc = ensure_pool(s, c)) return rc;
   c.args.full_stats = full_stats ? 1u : 0u;
   if (c.args.num_local_tiles == 0 && sx < 0) return VIMG_OK;
+  if (int rc = ensure_stage(s, c, st)) return rc;
+  if (!s->d_stage_kargs) HIP_TRY(hipMalloc(&s->d_stage_kargs, std::max(sizeof(StageKArgs), sizeof(Pool4KArgs))));
   HIP_TRY(hipMemsetAsync(s->d_counter, 0, 2 * sizeof(unsigned int), st));
   if (want_stats) HIP_TRY(hipMemsetAsync(s->d_stats, 0, sizeof(DeviceStats), st));
   DeviceStats* stats = want_stats ? s->d_stats : nullptr;
   if (c.lds_bytes > 48u * 1024u)   // very deep trees: ask for the large dynamic-LDS carve-out
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(s, c.pooled, c.wps, c.deep)),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(c.lds_bytes)));
-  hipLaunchKernelGGL(pick_kernel(s, c.pooled, c.wps, c.deep), dim3(c.grid), dim3(256), c.lds_bytes, st, s->d, c.args, d_out,
-                     stats, s->d_counter);
+    HIP_TRY(hipFuncSetAttribute(kernel_of(s, c), hipFuncAttributeMaxDynamicSharedMemorySize, int(c.lds_bytes)));
+  if (ev0 && c.sched != VIMG_SCHED_STAGE && c.sched != VIMG_SCHED_POOL4) HIP_TRY(hipEventRecord(ev0, st));
+  if (c.sched == VIMG_SCHED_STAGE)
+  {
+    // scene + launch parameters go to the block the stage functions read (stream-ordered, by value)
+    StageKArgs* blk = static_cast<StageKArgs*>(s->d_stage_kargs);
+    hipLaunchKernelGGL(stage_args_kernel, dim3(1), dim3(64), 0, st, StageKArgs{s->d, c.args, c.stage, d_out, stats}, blk);
+    if (ev0) HIP_TRY(hipEventRecord(ev0, st));
+    hipLaunchKernelGGL(pick_stage_kernel(s, c.deep), dim3(c.grid), dim3(256), c.lds_bytes, st,
+                       static_cast<const StageKArgs*>(blk));
+  }
+  else if (c.sched == VIMG_SCHED_POOL4) {
+    Pool4KArgs* blk = static_cast<Pool4KArgs*>(s->d_stage_kargs);
+    hipLaunchKernelGGL(pool4_args_kernel, dim3(1), dim3(64), 0, st, Pool4KArgs{s->d, c.args, d_out, stats, s->d_counter}, blk);
+    if (ev0) HIP_TRY(hipEventRecord(ev0, st));
+    hipLaunchKernelGGL(pick_pool4_kernel(s, c.deep, c.wps), dim3(c.grid), dim3(256), c.lds_bytes, st,
+                       static_cast<const Pool4KArgs*>(blk));
+  } else
+    hipLaunchKernelGGL(pick_kernel(s, c.pooled, c.wps, c.deep), dim3(c.grid), dim3(256), c.lds_bytes, st, s->d, c.args,
+                       d_out, stats, s->d_counter);
+  if (ev1) HIP_TRY(hipEventRecord(ev1, st));
   HIP_TRY(hipGetLastError());
   return VIMG_OK;
 }
+int launch_render(VimgDeviceScene* s, const VimgRenderParams* p, float* d_out, hipStream_t st,
+                  bool full_stats, bool want_stats, int sx, int sy) {
+  return enqueue_render(s, p, d_out, st, full_stats, want_stats, sx, sy);
+}
 
-// d_counter[1] is the error word of the last launch (raised by the pooled kernel's watchdog)
+// d_counter[1] is the error word of the last launch (raised by the pooled kernel's watchdog); the
+// staged kernel has its own in its control block
 int check_kernel_error(VimgDeviceScene* s) {
   unsigned int words[2] = {0, 0};
   HIP_TRY(hipMemcpy(words, s->d_counter, sizeof(words), hipMemcpyDeviceToHost));
-  if (words[1] != 0)
+  unsigned int stage_err = 0;
+  if (s->d_stage_ctl)
+    HIP_TRY(hipMemcpy(&stage_err, &static_cast<StageCtl*>(s->d_stage_ctl)->error.v, sizeof(stage_err), hipMemcpyDeviceToHost));
+  if (words[1] != 0 || stage_err != 0)
     return fail(VIMG_E_DEVICE, "render kernel watchdog: a wave waited for work that never came "
-                               "(the frame is incomplete)");
+                               "(the frame is incomplete), code " + std::to_string(words[1] | (stage_err << 8)));
   return VIMG_OK;
 }
 
@@ -447,6 +621,17 @@ int fetch_stats(VimgDeviceScene* s, const VimgRenderParams* p, VimgRenderStats* 
     std::fprintf(stderr, "[vimg diag] wave trips: descend %llu (lane visits %llu, util %.3f)  prim %llu (lane tests %llu, util %.3f)  main-loop iterations %llu\n",
                  ds.trip_descend, ds.internal, ds.trip_descend ? double(ds.internal) / (64.0 * ds.trip_descend) : 0.0,
                  ds.trip_prim, ds.prim, ds.trip_prim ? double(ds.prim) / (64.0 * ds.trip_prim) : 0.0, ds.iterations);
+#ifndef VIMG_PROFILE
+  if (getenv("VIMG_HIP_DIAG") && ds.prof[6 + 4]) {   // staged kernel: cycles and batch fill per stage
+    static const char* st_names[6] = {"finisher", "lambertian", "principled", "other", "walk", "looking for work"};   // (pool4: walk includes waiting)
+    unsigned long long total = 0;
+    for (int k = 0; k < 6; ++k) total += ds.prof[k];
+    for (int k = 0; k < 6; ++k)
+      std::fprintf(stderr, "[vimg stage] %-18s %14llu cyc %6.2f %%  batches %10llu  slots/batch %7.2f\n", st_names[k],
+                   ds.prof[k], 100.0 * double(ds.prof[k]) / double(total ? total : 1), k < 5 ? ds.prof[6 + k] : 0ull,
+                   (k < 5 && ds.prof[6 + k]) ? double(ds.prof[11 + k]) / double(ds.prof[6 + k]) : 0.0);
+  }
+#endif
 #ifdef VIMG_PROFILE
   if (getenv("VIMG_HIP_DIAG") && ds.prof[PF_TOTAL]) {
     static const char* names[PF_COUNT] = {"total", "v_load+logic+hit_info", "v_light_sample", "v_bsdf_sample",
@@ -484,7 +669,18 @@ int vimg_hip_init(int device_ordinal) {
   return VIMG_OK;
 }
 
+void vimg_hip_options_default(VimgHipOptions* o) {
+  if (!o) return;
+  int32_t* f = reinterpret_cast<int32_t*>(o);
+  for (size_t i = 1; i < sizeof(VimgHipOptions) / sizeof(int32_t); ++i) f[i] = VIMG_OPT_AUTO;
+  o->struct_size = sizeof(VimgHipOptions);
+}
+
 int vimg_hip_scene_upload(const VimgScene* sc, VimgDeviceScene** out) {
+  return vimg_hip_scene_upload_opts(sc, nullptr, out);
+}
+
+int vimg_hip_scene_upload_opts(const VimgScene* sc, const VimgHipOptions* opts, VimgDeviceScene** out) {
   if (!out) return fail(VIMG_E_INVALID, "null output pointer");
   *out = nullptr;
   if (g_device < 0) {
@@ -692,23 +888,20 @@ int vimg_hip_scene_upload(const VimgScene* sc, VimgDeviceScene** out) {
                           !(sc->background.col[0] == 0.f && sc->background.col[1] == 0.f &&
                             sc->background.col[2] == 0.f);
 
-  // kernel build: scenes beyond the on-chip caches are latency-bound and want more waves per
-  // SIMD; small scenes are VALU-bound and want the build that spills least
+  // LANE register budget: scenes beyond the on-chip caches are latency-bound and want more waves
+  // per SIMD; small scenes are VALU-bound and want the build that spills least
   s->waves_per_simd = (s->total_bytes > (32u << 20)) ? 3 : 2;
-  if (const char* e = getenv("VIMG_HIP_WAVES_PER_SIMD")) {
-    s->waves_per_simd = atoi(e);
-    s->wps_forced = true;
+  vimg_hip_options_default(&s->opt);
+  if (opts) {
+    // accept shorter (older) structs: fields beyond the caller's struct_size stay AUTO
+    const size_t n = std::min<size_t>(opts->struct_size, sizeof(VimgHipOptions));
+    if (n >= sizeof(uint32_t)) std::memcpy(&s->opt, opts, n);
+    s->opt.struct_size = sizeof(VimgHipOptions);
   }
-  // which scheduler: the pooled one (paths decoupled from lanes, render_pool_kernel.h) wherever a
-  // frame can fill its pools - measured on all five configurations (config 2 +36 %, 3 +36 %,
-  // 4 +24 %, 5 +14 % over the lane-bound kernel); make_launch falls back to the lane-bound kernel
-  // per launch for frames and shards too small for that
-  s->pooled = true;
-  if (const char* e = getenv("VIMG_HIP_POOL")) {
-    s->pooled = atoi(e) != 0;
-    s->pool_forced = s->pooled;
-  }
-  if (cam.res_x > 65535 || cam.res_y > 65535) s->pooled = false;   // slots pack pixel coordinates
+  options_from_env(&s->opt);
+  if (s->opt.scheduler != VIMG_OPT_AUTO && (s->opt.scheduler < VIMG_SCHED_LANE || s->opt.scheduler > VIMG_SCHED_POOL4))
+    return bail(fail(VIMG_E_INVALID, "options: unknown scheduler"));
+  s->too_wide = (cam.res_x > 65535 || cam.res_y > 65535);   // slots pack pixel coordinates in 16 bits
   hipDeviceProp_t prop{};
   if (hipGetDeviceProperties(&prop, g_device) != hipSuccess) return bail(fail(VIMG_E_DEVICE, "hipGetDeviceProperties failed"));
   s->num_cus = static_cast<uint32_t>(prop.multiProcessorCount);
@@ -727,12 +920,14 @@ int vimg_hip_scene_free(VimgDeviceScene* s) {
   if (s->d_frame) (void)hipFree(s->d_frame);
   if (s->d_pool_cold) (void)hipFree(s->d_pool_cold);
   if (s->d_pool_state) (void)hipFree(s->d_pool_state);
+  for (void* q : {s->d_stage_ctl, s->d_stage_kargs, s->d_stage_rings, s->d_stage_pix_ring, s->d_stage_pix_state, s->d_stage_slots})
+    if (q) (void)hipFree(q);
   delete s;
   return VIMG_OK;
 }
 
-const char* vimg_hip_scene_kernel(const VimgDeviceScene* s) {
-  if (!s) return "";
+const char* vimg_hip_launch_kernel(const VimgDeviceScene* s, const VimgRenderParams* p) {
+  if (!s || !p) return "";
   static const char* names[2][2][2] = {
       {{"render_kernel<false,2>", "render_kernel<false,3>"}, {"render_kernel<true,2>", "render_kernel<true,3>"}},
       {{"render_pool_kernel<false,2>", "render_pool_kernel<false,3>"},
@@ -740,11 +935,22 @@ const char* vimg_hip_scene_kernel(const VimgDeviceScene* s) {
   static const char* deep_names[2][2] = {
       {"render_pool_kernel<false,2,deep>", "render_pool_kernel<false,3,deep>"},
       {"render_pool_kernel<true,2,deep>", "render_pool_kernel<true,3,deep>"}};
-  // the choice between the two schedulers is made per launch: report the one of a whole frame
-  const VimgRenderParams whole{VIMG_INTEGRATOR_MIS, 64, 1, 0, 1};
-  const LaunchCfg c = make_launch(s, &whole, -1, -1);
+  static const char* stage_names[2][2] = {{"render_stage_kernel<false>", "render_stage_kernel<false,deep>"},
+                                          {"render_stage_kernel<true>", "render_stage_kernel<true,deep>"}};
+  if (p->tile_world == 0 || p->tile_rank >= p->tile_world) return "";
+  const LaunchCfg c = make_launch(s, p, -1, -1);
+  static const char* pool4_names[2][2] = {{"render_pool4_kernel<false>", "render_pool4_kernel<false,deep>"},
+                                          {"render_pool4_kernel<true>", "render_pool4_kernel<true,deep>"}};
+  if (c.sched == VIMG_SCHED_STAGE) return stage_names[s->textured ? 1 : 0][c.deep ? 1 : 0];
+  if (c.sched == VIMG_SCHED_POOL4) return pool4_names[s->textured ? 1 : 0][c.deep ? 1 : 0];
   if (c.deep) return deep_names[s->textured ? 1 : 0][c.wps >= 3 ? 1 : 0];
   return names[c.pooled ? 1 : 0][s->textured ? 1 : 0][c.wps >= 3 ? 1 : 0];
+}
+
+const char* vimg_hip_scene_kernel(const VimgDeviceScene* s) {
+  // the scheduler is chosen per launch: report the one of a whole frame
+  const VimgRenderParams whole{VIMG_INTEGRATOR_MIS, 64, 1, 0, 1};
+  return vimg_hip_launch_kernel(s, &whole);
 }
 
 int64_t vimg_hip_scene_bytes(const VimgDeviceScene* s) {
@@ -863,17 +1069,9 @@ int vimg_hip_time_renders(VimgDeviceScene* s, const VimgRenderParams* p, void* d
   std::vector<hipEvent_t> ev(size_t(steps) * 2);
   for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
   for (int i = 0; i < steps; ++i) {
-    // the counter reset is part of a launch's prologue; the events bracket the kernel only
-    HIP_TRY(hipMemsetAsync(s->d_counter, 0, 2 * sizeof(unsigned int), g_stream));
-    LaunchCfg c = make_launch(s, p, -1, -1);
-    if (int rc = ensure_pool(s, c)) return rc;
-    if (c.lds_bytes > 48u * 1024u)
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(s, c.pooled, c.wps, c.deep)),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(c.lds_bytes)));
-    HIP_TRY(hipEventRecord(ev[2 * i], g_stream));
-    hipLaunchKernelGGL(pick_kernel(s, c.pooled, c.wps, c.deep), dim3(c.grid), dim3(256), c.lds_bytes, g_stream, s->d, c.args,
-                       static_cast<float*>(d_out), static_cast<DeviceStats*>(nullptr), s->d_counter);
-    HIP_TRY(hipEventRecord(ev[2 * i + 1], g_stream));
+    // the counter / queue resets are part of a launch's prologue; the events bracket the kernel only
+    if (int rc2 = enqueue_render(s, p, static_cast<float*>(d_out), g_stream, false, false, -1, -1, ev[2 * i], ev[2 * i + 1]))
+      return rc2;
   }
   HIP_TRY(hipStreamSynchronize(g_stream));
   if (int rc2 = check_kernel_error(s)) return rc2;

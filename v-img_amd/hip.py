@@ -67,12 +67,18 @@ def init(device=0):
 
 
 class DeviceScene:
-    """A scene resident in HBM (vimg_hip_scene_upload)."""
+    """A scene resident in HBM (vimg_hip_scene_upload_opts).  `options`: abi.HipOptions, or keyword
+    arguments for one (scheduler="lane" | "pool" | "stage", pool_segments=..., ...); nothing given
+    = the library's policy."""
 
-    def __init__(self, host_scene: HostScene):
+    def __init__(self, host_scene: HostScene, options=None, **opt_kw):
         self._lib = _lib()
         h = C.c_void_p()
-        _check(self._lib.vimg_hip_scene_upload(host_scene.view, C.byref(h)))
+        if options is None and opt_kw:
+            options = abi.HipOptions(**opt_kw)
+        self.options = options
+        _check(self._lib.vimg_hip_scene_upload_opts(host_scene.view, C.byref(options) if options is not None else None,
+                                                    C.byref(h)))
         self._h = h
         self.resolution = host_scene.resolution
 
@@ -86,12 +92,7 @@ class DeviceScene:
 
     def kernel_for(self, params):
         """Name of the kernel a launch with these parameters gets (the scheduler is chosen per launch)."""
-        fn = getattr(self._lib, "vimg_hip_launch_kernel", None)
-        if fn is None:
-            return self.kernel
-        fn.restype = C.c_char_p
-        fn.argtypes = [C.c_void_p, C.c_void_p]
-        return fn(self._h, C.byref(params)).decode()
+        return self._lib.vimg_hip_launch_kernel(self._h, C.byref(params)).decode()
 
     def shard_pixels(self, params):
         return _check(self._lib.vimg_hip_shard_pixels(self._h, C.byref(params)))
