@@ -77,7 +77,10 @@ VD uint32_t uni(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_read
 
 // One vertex batch (<= 64 slots) of queue `cls`.  FIN: the finisher queue (cls 0); MT: material the
 // shading is specialised for (-1 = any).  The body is render_pool_kernel's vertex stage.
-template <bool TEX, bool FIN, int MTC>
+// (WPS: the register budget of the kernel that calls it - a copy per budget, so that the three-wave
+// build's callees get its 168 registers: 104 of them are caller-saved, and a callee that stays
+// within those saves nothing - 8 to 29 saved registers per call instead of 32 to 48)
+template <bool TEX, bool FIN, int MTC, int WPS>
 __device__ __noinline__ void pool4_vertex(uint32_t k_lo, uint32_t k_hi, VIMG_LDS uint32_t* pool,
                                           VIMG_LDS Pool4Wave* pw, uint32_t cls) {
   const Pool4KPtr K = pool4_kargs(k_lo, k_hi);
@@ -287,6 +290,10 @@ __device__ __noinline__ void pool4_vertex(uint32_t k_lo, uint32_t k_hi, VIMG_LDS
   bool has_s = false, has_r = false;
   f3 shadow_d{0.f, 0.f, 1.f}, nee_contrib{0.f, 0.f, 0.f};
   float shadow_max_t = 0.f;
+  // (a finisher batch never holds a vertex to shade: the walk sends every hit on a non-emitter to
+  // its material's class - class 3 for everything under the material integrator - so the finisher
+  // build carries no shading code at all)
+  if constexpr (!finisher_batch) {
   if (material_mode && at_vertex) {
     // mat_integrator.cpp:24-78: BSDF sampling only, throughput *= emitted + eval/pdf
     gptr<VimgMaterial> m = g.materials + hit.mat;
@@ -341,6 +348,7 @@ __device__ __noinline__ void pool4_vertex(uint32_t k_lo, uint32_t k_hi, VIMG_LDS
       }
     }
     at_vertex = false;
+  }
   }
   // A batch of class 1 holds Lambertian vertices only and one of class 2 Principled ones only
   // (three-class sorting), so the shading code exists in a build per material with the type
@@ -423,8 +431,8 @@ __device__ __noinline__ void pool4_vertex(uint32_t k_lo, uint32_t k_hi, VIMG_LDS
     primary = false;
     if (!has_s && !has_r) finish = true;
   };
-  if (at_vertex) {
-    shade_vertex(std::integral_constant<int, MTC>{});
+  if constexpr (!finisher_batch) {
+    if (at_vertex) shade_vertex(std::integral_constant<int, MTC>{});
   }
 
   // ---- finished samples: accumulate, pixel write-back, next pixel, next camera ray
@@ -749,13 +757,13 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
         pw->skip_fin = skip_fin ? 1u : 0u, pw->idle_polls = idle_polls;
       }
       if (cls == 0u)
-        pool4_vertex<TEX, true, -1>(k_lo, k_hi, pool, pw, cls);
+        pool4_vertex<TEX, true, -1, WPS>(k_lo, k_hi, pool, pw, cls);
       else if (cls == 1u && A.pool_classes == 3u)
-        pool4_vertex<TEX, false, int(VIMG_MAT_LAMBERTIAN)>(k_lo, k_hi, pool, pw, cls);
+        pool4_vertex<TEX, false, int(VIMG_MAT_LAMBERTIAN), WPS>(k_lo, k_hi, pool, pw, cls);
       else if (cls == 2u && A.pool_classes == 3u)
-        pool4_vertex<TEX, false, int(VIMG_MAT_PRINCIPLED)>(k_lo, k_hi, pool, pw, cls);
+        pool4_vertex<TEX, false, int(VIMG_MAT_PRINCIPLED), WPS>(k_lo, k_hi, pool, pw, cls);
       else
-        pool4_vertex<TEX, false, -1>(k_lo, k_hi, pool, pw, cls);
+        pool4_vertex<TEX, false, -1, WPS>(k_lo, k_hi, pool, pw, cls);
       qw_head = uni(pw->qw_head), qw_count = uni(pw->qw_count);
       qv_head0 = uni(pw->qv_head[0]), qv_head1 = uni(pw->qv_head[1]), qv_head2 = uni(pw->qv_head[2]), qv_head3 = uni(pw->qv_head[3]);
       qv_count0 = uni(pw->qv_count[0]), qv_count1 = uni(pw->qv_count[1]), qv_count2 = uni(pw->qv_count[2]), qv_count3 = uni(pw->qv_count[3]);
