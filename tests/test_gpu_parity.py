@@ -302,6 +302,80 @@ def test_tile_shards_reassemble_to_the_single_gpu_image():
         assert np.array_equal(host, full.cpu().numpy())
 
 
+@pytest.mark.parametrize("name", ["config4", "config5"])
+def test_config4_and_5_standins_as_2_4_8_shards(name):
+    """BASELINE configs[3] and [4] in the form they are stated - tile-sharded over 2 / 4 / 8 GPUs -
+    on their stand-ins (deep trees, textures, normal / RG maps, HDRI + thin lens): every shard of
+    every split rendered on this GPU (tile t -> rank t % N, include/integrators.h:57-65,101) with
+    the scheduler the policy picks for it, and with the pooled one asked for by name; the shards
+    reassemble, on the device, to the bits of the whole frame.  Stats add up exactly."""
+    import torch
+    from vimg_amd import dist as vdist
+    s = {"config4": lambda: scenes.config4_scene(res=(200, 112), n_lat=64, env=(128, 64)),
+         "config5": lambda: scenes.config5_scene(res=(200, 112), n=80, tex=64)}[name]()
+    w, h = s.resolution
+    kw = dict(samples=6, depth=10)
+    d = _dev(s)
+    full, st_full = d.render(s.default_params(**kw))
+    pooled = _dev_opts(s, scheduler="pool4", pool_slots=40)
+    for world in (2, 4, 8):
+        for dev in (d, pooled):
+            stride = vdist.shard_stride_pixels(w, h, world)
+            gathered = torch.zeros((world, stride, 3), dtype=torch.float32, device="cuda")
+            tot = {}
+            for r in range(world):
+                pr = s.default_params(tile_rank=r, tile_world=world, **kw)
+                assert dev.shard_pixels(pr) == 64 * len(vdist.shard_tiles(w, h, r, world))
+                _, st = dev.render(pr, out=gathered[r])
+                for k, v in st.as_dict().items():
+                    tot[k] = tot.get(k, 0) + v
+            img = dev.assemble_shards(gathered, world, stride)
+            assert torch.equal(img, full), (name, world, dev.kernel)
+            assert tot == st_full.as_dict(), (name, world)
+
+
+@pytest.mark.parametrize("name", ["config3", "config4", "config5"])
+def test_config_standins_at_full_size_properties(name):
+    """The stand-ins of BASELINE configs 3-5 at the sizes SURVEY.md 8d gives them (1366x1024 Disney
+    array under a 1024x512 env map; 1366x768 with 635 K / 1.0 M triangles), where the oracle
+    cannot render the frame in test time: size-independent properties - finite, deterministic,
+    the policy's scheduler equals the lane-bound kernel bit for bit, plausible rays per path,
+    an eighth of the frame as a shard equals the same pixels of the frame - and three
+    single-pixel traces against the oracle at the full sample count of the test."""
+    import torch
+    from vimg_amd import dist as vdist
+    s = {"config3": scenes.config3_scene, "config4": scenes.config4_scene,
+         "config5": lambda: scenes.config5_scene(n=700)}[name]()
+    w, h = s.resolution
+    assert (w, h) == ((1366, 1024) if name == "config3" else (1366, 768))
+    p = s.default_params(samples=4, depth=16)
+    d = _dev(s)
+    assert d.kernel.startswith("render_pool4_kernel")
+    img, st = d.render_to_host(p)
+    assert st.paths == w * h * 4 and st.nan_samples == 0
+    assert np.isfinite(img).all() and img.min() >= 0
+    again, st2 = d.render_to_host(p)
+    assert np.array_equal(img.view(np.uint32), again.view(np.uint32)) and st.as_dict() == st2.as_dict()
+    lane, st_lane = _dev_opts(s, scheduler="lane").render_to_host(p)
+    assert np.array_equal(img.view(np.uint32), lane.view(np.uint32)) and st.as_dict() == st_lane.as_dict()
+    assert 1.5 < st.rays / st.paths < 12.0
+    p8 = s.default_params(samples=4, depth=16, tile_rank=5, tile_world=8)
+    slab, _ = d.render(p8)
+    stride = vdist.shard_stride_pixels(w, h, 8)
+    gathered = np.zeros((8, stride, 3), dtype=np.float32)
+    gathered[5, :slab.shape[0]] = slab.cpu().numpy()
+    mine = vdist.assemble_numpy(gathered, w, h, 8)
+    mask = np.zeros((8, stride, 3), dtype=np.float32)
+    mask[5, :slab.shape[0]] = 1
+    own = vdist.assemble_numpy(mask, w, h, 8)[..., 0] > 0
+    assert np.array_equal(mine[own].view(np.uint32), img[own].view(np.uint32))
+    for (x, y) in ((w // 2, h // 2), (w // 3, (2 * h) // 3), (w - 7, 11)):
+        ref = O.trace_pixel(s, p, x, y)
+        got = d.trace_pixel(p, x, y)
+        assert np.allclose(got, ref, rtol=2e-5, atol=1e-6), (name, x, y, got, ref)
+        assert np.allclose(img[h - 1 - y, x], ref, rtol=2e-5, atol=1e-6)
+
+
 def test_full_size_properties_disney_spheres():
     """BASELINE config 2 at full resolution, few samples: size-independent properties."""
     s = scenes.json_scene("disney_spheres.json")

@@ -326,10 +326,10 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   LaunchCfg c{};
   const VimgHipOptions& o = s->opt;
   const uint64_t items = (sx >= 0) ? 1 : uint64_t(local_tiles(s, p)) * 64u;
-  // ---- which scheduler.  Policy (AUTO): the pooled scheduler in its four-waves-per-SIMD build;
-  // launches too small to fill its pools - fewer pixels than 1.5 x the slots in flight: test images,
-  // trace_pixel, very thin shards - go to the lane-bound kernel (decided below, once the pool size
-  // is known).  The staged kernel (global queues) runs when asked for by name.
+  // ---- which scheduler.  Policy (AUTO): the pooled scheduler with its vertex stage as calls
+  // (pool4); launches with too few pixels per wave for pools of 64 slots - test images,
+  // trace_pixel, thin shards - go to the lane-bound kernel (decided below, where the pool is
+  // sized).  The first pooled kernel and the staged kernel (global queues) run when asked for by name.
   int sched = sched_override ? sched_override : (o.scheduler == VIMG_OPT_AUTO ? 0 : o.scheduler);
   const bool by_policy = (sched == 0);
   if (!for_render) sched = VIMG_SCHED_LANE;   // probes and the heatmap only need the LDS layout
@@ -399,7 +399,23 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
     slots = std::min(slots, 256u);
     if (o.pool_slots != VIMG_OPT_AUTO) slots = std::min(slots, uint32_t(std::max(0, o.pool_slots)));
     a.pool_slots = std::max(slots, 8u);
-    if (sched == VIMG_SCHED_POOL4) a.pool_slots &= ~1u;   // even: every wave's cold region starts on a 64-byte line
+    if (sched == VIMG_SCHED_POOL4) {
+      // Pixels are the unit of parallelism (one sequential RNG stream per pixel): a launch with few
+      // pixels per wave is fastest with pools of about pixels / 2.4 slots (half of config 2, 720 K
+      // pixels on 3072 waves: 186 slots 310 ms, 128: 241, 96: 239, 80: 259), and below 64 slots per
+      // wave the lane-bound kernel wins (a quarter of config 2: pool4 237 ms, lane-bound 205; an
+      // eighth: 222 / 137) - the pooled scheduler's hop latency times the longest pixel's chain of
+      // path vertices is then the whole frame time.  By policy only; a pool size asked for by name stands.
+      if (by_policy && !sched_override && o.pool_slots == VIMG_OPT_AUTO) {
+        if (sx >= 0) return make_launch(s, p, sx, sy, for_render, VIMG_SCHED_LANE);   // trace_pixel: one path
+        int per_cu_guess = 3;   // workgroups per CU of this build (checked against the runtime below)
+        const uint64_t waves = uint64_t(s->num_cus) * uint32_t(per_cu_guess) * 4u;
+        const uint64_t want = items * 10u / (waves * 24u);
+        if (want < 64u) return make_launch(s, p, sx, sy, for_render, VIMG_SCHED_LANE);
+        a.pool_slots = static_cast<uint32_t>(std::min<uint64_t>(a.pool_slots, want));
+      }
+      a.pool_slots &= ~1u;   // even: every wave's cold region starts on a 64-byte line
+    }
     c.lds_bytes += 4u * ((slot_bytes * a.pool_slots + 15u) & ~15u) + leaf_bytes;
   }
   StageArgs& g = c.stage;
@@ -441,10 +457,6 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   a.pool_seg_len = p->samples;
   if (a.pool_slots && sx < 0) {
     const uint64_t in_flight = uint64_t(c.grid) * 4u * a.pool_slots;
-    // A frame with fewer pixels than 1.5 x the slots in flight does not fill the pools (904x400:
-    // pooled 3.1, lane-bound 4.5 Grays/s): such launches go to the lane-bound kernel, unless the
-    // pooled scheduler was asked for by name.
-    if (by_policy && !sched_override && items * 2u < in_flight * 3u) return make_launch(s, p, sx, sy, for_render, VIMG_SCHED_LANE);
     // Segments: the tail of a frame is one segment long, and every hand-over costs a little
     // (config 2, 3.5 pool generations per frame: 1 segment 6.8, 4: 7.5, 8: 7.6, 16-32: 7.6 Grays/s;
     // 3600x1600, 14 generations: 1 segment 7.9, 4: 7.7) - about 56 segments per generation count,
