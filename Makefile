@@ -22,7 +22,7 @@ ORAFLAGS  := -std=c++20 -O3 -march=x86-64-v3 -fPIC -shared -ffp-contract=off -pt
 HIPFLAGS  := --offload-arch=$(ARCH) -std=c++20 -O3 -fPIC -shared -ffp-contract=off -fno-slp-vectorize \
              -fno-fast-math -Iinclude -Wall -Wno-unused-function
 
-all: host hip oracle cli
+all: host hip oracle oracle-avx2 cli
 host: $(LIBDIR)/libvimg_host.so
 hip: $(LIBDIR)/libvimg_hip.so
 oracle: oracle/liboracle.so
@@ -57,7 +57,15 @@ oracle/liboracle.so: $(ORASRC) $(ORAHDR) Makefile
 oracle/liboracle_libmf.so: $(ORASRC) $(ORAHDR) Makefile
 	$(CXX) $(ORAFLAGS) -DORACLE_LIBM_FLOAT=1 $(ORASRC) -o $@
 
+# TIMING build of the oracle (never a parity partner): the reference's AVX2 two-sibling slab path
+# (include/simd_hit.h:121-156, include/bvh.h:109-116) with the optimisation level and contraction
+# default of the reference's release build; x86-64-v3 (AVX2 + FMA) instead of -march=native because
+# the library is built in the build container and timed on the GPU box's host CPU.
+oracle-avx2: oracle/liboracle_avx2.so
+oracle/liboracle_avx2.so: $(ORASRC) $(ORAHDR) Makefile
+	$(CXX) -std=c++20 -O3 -march=x86-64-v3 -fPIC -shared -pthread -Wall -Iinclude -DORACLE_AVX2_TIMING=1 $(ORASRC) -o $@
+
 clean:
 	rm -f $(LIBDIR)/*.so oracle/*.so
 
-.PHONY: all host hip oracle cli clean prof
+.PHONY: all host hip oracle oracle-avx2 cli clean prof

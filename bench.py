@@ -87,20 +87,40 @@ def measured_traffic(workload):
 
 
 def cpu_baseline(spp):
-    """The CPU port (oracle/) timed on this box's host cores on a bounded sample of the same
-    workload: the same 1800x800 pixels, the first `spp` of the 512 samples."""
+    """The CPU side timed on this box's host cores on a bounded sample of the same workload: the
+    same 1800x800 pixels, the first `spp` of the 512 samples, all hardware threads of the job's
+    CPU share.  Two builds of the CPU restatement (oracle/) are timed:
+      * the baseline SURVEY.md 8d defines - `value`: -O3 with the reference's AVX2 two-sibling slab
+        test on an approximate reciprocal (include/simd_hit.h:121-156, include/bvh.h:109-116), i.e.
+        what the reference's release binary runs (oracle/liboracle_avx2.so; its image differs from
+        the scalar path's, quirk Q9, so it is timed, never compared);
+      * the scalar parity partner the GPU image is bit-compared with (oracle/liboracle.so:
+        -ffp-contract=off, exact 1/x) - `scalar_parity_build`.
+    The reference itself cannot be built here, hence kind = "port"."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     scene = load_scene((1800, 800))
     params = scene.default_params(samples=spp)
-    t0 = time.perf_counter()
     share = cpu_share()
-    _, st, threads = O.render(scene, params, threads=share)
-    dt = time.perf_counter() - t0
-    return {"value": round(st.rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": int(threads),
-            "kind": "port", "seconds": round(dt, 2),
-            "sample": f"disney_spheres.json 1800x800, first {spp} of 512 spp (same pixels, same "
-                      f"seeds), oracle/liboracle.so on {threads} threads"}
+    legs = {}
+    for key, name in (("avx2", "liboracle_avx2.so"), ("scalar", "liboracle.so")):
+        lib = O.load(name)
+        t0 = time.perf_counter()
+        _, st, threads = O.render(scene, params, threads=share, lib=lib)
+        dt = time.perf_counter() - t0
+        legs[key] = {"value": round(st.rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": int(threads),
+                     "seconds": round(dt, 2), "library": "oracle/" + name}
+    out = dict(legs["avx2"])
+    out.update({
+        "kind": "port",
+        "build": "g++ -O3 -march=x86-64-v3, AVX2 two-sibling slab test on _mm256_rcp_ps (the reference's "
+                 "release path); README-derived figure for the reference itself: ~74 Mrays/s on a Ryzen 7 7700",
+        "sample": f"disney_spheres.json 1800x800, first {spp} of 512 spp (same pixels, same seeds), "
+                  f"{legs['avx2']['cores']} threads",
+        "scalar_parity_build": dict(legs["scalar"], build="g++ -O3 -march=x86-64-v3 -ffp-contract=off, scalar slab "
+                                                          "test with exact 1/x: the build the GPU image is bit-compared with"),
+    })
+    return out
 
 
 def self_launch(args):

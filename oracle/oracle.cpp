@@ -16,6 +16,10 @@
 
 #include "omath.h"
 
+#if defined(ORACLE_AVX2_TIMING) && ORACLE_AVX2_TIMING
+#include <immintrin.h>
+#endif
+
 using namespace om;
 
 namespace {
@@ -438,6 +442,65 @@ inline float slab_intersect_aabb_array(const Ray& ray, vec3 inv, const float* bb
   return (tBoxMin <= tBoxMax) ? tBoxMin : kInf;
 }
 
+#if defined(ORACLE_AVX2_TIMING) && ORACLE_AVX2_TIMING
+// ---- TIMING BUILD ONLY (liboracle_avx2.so, `make oracle-avx2`): the reference's AVX2 slab path,
+// which is what its release binary runs on an AVX2 machine - ray_1aabb_slab / ray_2aabb_slab
+// (reference include/simd_hit.h:37-156) on a ~12-bit reciprocal of the direction
+// (_mm256_rcp_ps, include/bvh.h:109-116).  Its results differ from the scalar path's (SURVEY
+// quirk Q9: 27 % of config-2 pixels at 4 spp), so this build is never a parity partner: bench.py
+// times it as the CPU baseline SURVEY.md 8d defines, next to the scalar build.
+struct SimdRay {
+  __m256 o, inv;
+};
+inline SimdRay simd_ray(const Ray& ray) {
+  SimdRay r;
+  __m256 d = _mm256_set_ps(1.f, ray.dir.z, ray.dir.y, ray.dir.x, 1.f, ray.dir.z, ray.dir.y, ray.dir.x);
+  r.inv = _mm256_rcp_ps(d);
+  r.o = _mm256_set_ps(0.f, ray.o.z, ray.o.y, ray.o.x, 0.f, ray.o.z, ray.o.y, ray.o.x);
+  return r;
+}
+inline float hmax4(__m128 x) {   // max of the four lanes (horizontal_max_128, simd_hit.h:13-20)
+  __m128 s1 = _mm_shuffle_ps(x, x, _MM_SHUFFLE(0, 0, 3, 2));
+  __m128 m1 = _mm_max_ps(x, s1);
+  __m128 s2 = _mm_shuffle_ps(m1, m1, _MM_SHUFFLE(0, 0, 0, 1));
+  return _mm_cvtss_f32(_mm_max_ps(m1, s2));
+}
+inline float hmin4(__m128 x) {   // horizontal_min_128, simd_hit.h:23-33
+  __m128 s1 = _mm_shuffle_ps(x, x, _MM_SHUFFLE(0, 0, 3, 2));
+  __m128 m1 = _mm_min_ps(x, s1);
+  __m128 s2 = _mm_shuffle_ps(m1, m1, _MM_SHUFFLE(0, 0, 0, 1));
+  return _mm_cvtss_f32(_mm_min_ps(m1, s2));
+}
+// ray_1aabb_slab, simd_hit.h:37-68: one box, the fourth lane carries minT / maxT
+inline float simd_slab1(const float* mins, const float* maxs, const SimdRay& sr, const Ray& r) {
+  const __m128 o = _mm256_castps256_ps128(sr.o), inv = _mm256_castps256_ps128(sr.inv);
+  __m128 lo = _mm_mul_ps(_mm_sub_ps(_mm_loadu_ps(mins), o), inv);
+  __m128 hi = _mm_mul_ps(_mm_sub_ps(_mm_loadu_ps(maxs), o), inv);
+  __m128 mn = _mm_min_ps(lo, hi), mx = _mm_max_ps(lo, hi);
+  float t_min = hmax4(_mm_insert_ps(mn, _mm_set_ss(r.minT), 0b00110000));
+  float t_max = hmin4(_mm_insert_ps(mx, _mm_set_ss(r.maxT), 0b00110000));
+  return (t_min <= t_max) ? t_min : kInf;
+}
+// ray_2aabb_slab, simd_hit.h:121-156: both sibling boxes in one 8-lane pass.  `mins` points at
+// left.min (3 floats) followed by right.min, `maxs` at left.max followed by right.max, as
+// BB_mins_maxes stores them; the permute sorts the eight loaded floats into two 4-lane halves.
+inline void simd_slab2(const float* mins, const float* maxs, const SimdRay& sr, const Ray& r, float& t1,
+                       float& t2) {
+  const __m256i perm = _mm256_set_epi32(6, 5, 4, 3, 7, 2, 1, 0);
+  __m256 lo = _mm256_permutevar8x32_ps(_mm256_loadu_ps(mins), perm);
+  lo = _mm256_mul_ps(_mm256_sub_ps(lo, sr.o), sr.inv);
+  __m256 hi = _mm256_permutevar8x32_ps(_mm256_loadu_ps(maxs), perm);
+  hi = _mm256_mul_ps(_mm256_sub_ps(hi, sr.o), sr.inv);
+  __m256 mn = _mm256_min_ps(lo, hi), mx = _mm256_max_ps(lo, hi);
+  mn = _mm256_blend_ps(mn, _mm256_set1_ps(r.minT), 0b10001000);
+  mx = _mm256_blend_ps(mx, _mm256_set1_ps(r.maxT), 0b10001000);
+  const float lo1 = hmax4(_mm256_castps256_ps128(mn)), lo2 = hmax4(_mm256_extractf128_ps(mn, 1));
+  const float hi1 = hmin4(_mm256_castps256_ps128(mx)), hi2 = hmin4(_mm256_extractf128_ps(mx, 1));
+  t1 = (lo1 <= hi1) ? lo1 : kInf;
+  t2 = (lo2 <= hi2) ? lo2 : kInf;
+}
+#endif
+
 // difference_of_products(_double) — reference include/geometry/triangle.h:11-21
 inline float difference_of_products(float a, float b, float c, float d) {
   float cd = c * d;
@@ -659,9 +722,14 @@ bool bvh_hit(const Ctx& c, Ray& ray, HitInfo* out) {
   const VimgBVH& bvh = s->bvh;
   if (bvh.num_nodes == 0) return false;
   if (c.cnt) (ANY_HIT ? c.cnt->shadow : c.cnt->closest)++;
-  vec3 inv{1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z};
   const float* bb = bvh.bb_mins_maxes;
+#if defined(ORACLE_AVX2_TIMING) && ORACLE_AVX2_TIMING
+  const SimdRay sr = simd_ray(ray);
+  float root_hit = simd_slab1(bb + 0, bb + 6, sr, ray);
+#else
+  vec3 inv{1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z};
   float root_hit = slab_intersect_aabb_array(ray, inv, bb + 0, bb + 6);
+#endif
   if (std::isinf(root_hit)) return false;
   uint32_t stack[128];
   int sp = 0;
@@ -691,9 +759,14 @@ bool bvh_hit(const Ctx& c, Ray& ray, HitInfo* out) {
       uint32_t first_child = node.first_index;
       uint32_t sec_child = first_child + 1;
       size_t l_min = size_t{first_child} * 2 + 2, l_max = l_min + 2;
+#if defined(ORACLE_AVX2_TIMING) && ORACLE_AVX2_TIMING
+      float bb_hit1, bb_hit2;
+      simd_slab2(bb + 3 * l_min, bb + 3 * l_max, sr, ray, bb_hit1, bb_hit2);
+#else
       size_t r_min = l_min + 1, r_max = l_max + 1;
       float bb_hit1 = slab_intersect_aabb_array(ray, inv, bb + 3 * l_min, bb + 3 * l_max);
       float bb_hit2 = slab_intersect_aabb_array(ray, inv, bb + 3 * r_min, bb + 3 * r_max);
+#endif
       if (ANY_HIT) {
         if (!std::isinf(bb_hit1)) stack[sp++] = first_child;
         if (!std::isinf(bb_hit2)) stack[sp++] = sec_child;

@@ -822,3 +822,26 @@ def test_lbvh_builder_gives_a_valid_tree_and_the_same_picture(name):
     assert gst.paths == cst.paths and abs(gst.rays - cst.rays) <= max(8, 2e-3 * cst.rays)
     same = (gpu.view(np.uint32) == sah_img.view(np.uint32)).all(axis=-1).mean()
     assert same > 0.97 and abs(gpu.mean() - sah_img.mean()) <= 0.03 * abs(sah_img.mean()) + 1e-6
+
+
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` with no rendezvous in the environment must start the ranks itself
+    (fresh child processes; the driver invokes it exactly like this) and relay one JSON line.
+    Rehearsal form: both ranks on this GPU, host-staged gather (gloo), strong scaling on a small
+    frame, assembled image verified against the single-GPU frame."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                        "--one-device", "--spp", "8", "--steps", "1", "--warmup", "0", "--no-cpu", "--verify",
+                        "--res", "456", "200"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert "verify: assembled frame is bit-identical" in r.stderr
+    assert 0 < out["efficiency"] <= 1.5
