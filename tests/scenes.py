@@ -44,7 +44,7 @@ def _grid_mesh(n, size, height_fn, uv_scale=1.0):
     return verts, idx, nrm.astype(np.float32), uv
 
 
-def feature_scene(res=(96, 64), seed=7, envmap=True, lens=True):
+def feature_scene(res=(96, 64), seed=7, envmap=True, lens=True, rg_shape=(8, 8)):
     """Procedural scene exercising every feature on the path that the JSON format cannot
     express: mesh with interpolated normals and two uv sets, mip-mapped image texture, normal
     map, metallic-roughness map, checkerboard, Principled + Lambertian + glass + emissive quad,
@@ -63,7 +63,7 @@ def feature_scene(res=(96, 64), seed=7, envmap=True, lens=True):
     nm[..., 2] = 1.0
     nm /= np.linalg.norm(nm, axis=2, keepdims=True)
     t_nm = s.add_texture_image(nm, abi.WRAP_REPEAT, abi.WRAP_REPEAT)
-    rg = rng.random((8, 8, 2), dtype=np.float32) * 0.8 + 0.1
+    rg = rng.random((rg_shape[1], rg_shape[0], 2), dtype=np.float32) * 0.8 + 0.1    # (width, height) of the map
     t_rg = s.add_texture_rg(rg, abi.WRAP_REPEAT, abi.WRAP_CLAMP)
     t_white = s.add_texture_const((0.73, 0.73, 0.73))
     t_checker = s.add_texture_checker(8, 8, (0.8, 0.8, 0.8), (0.15, 0.15, 0.2))

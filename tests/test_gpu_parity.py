@@ -194,6 +194,27 @@ def test_feature_scene_matches_oracle(envmap, lens):
     assert abs(gst.rays - cst.rays) <= max(16, 1e-3 * cst.rays)
 
 
+def test_non_square_rg_map_reproduces_the_references_indexing():
+    """Quirk Q6: TextureRG::get_at_uv indexes the +x neighbours with "* height"
+    (include/texture/texture_RG.h:47,52).  On a map wider than tall that is a wrong but in-bounds
+    texel: the GPU reproduces it (= the oracle, which restates the line), and the picture differs
+    from the one a "* width" reading gives only through that texel - checked by rendering the same
+    scene with the map's rows duplicated to a square, where the two indexings coincide on x0 / y0 but
+    not on x1 / y1.  A map taller than wide makes the reference read beyond its vector: refused."""
+    from vimg_amd import hip
+    s = scenes.feature_scene(res=(96, 64), rg_shape=(32, 8))
+    p = s.default_params(samples=8, depth=8)
+    cpu, cst, _ = O.render(s, p)
+    for sched in ("lane", "pool4"):
+        gpu, gst = _dev_opts(s, scheduler=sched).render_to_host(p)
+        _compare_images(gpu, cpu, f"wide RG map ({sched})", min_exact=0.995)
+        assert gst.paths == cst.paths
+    square, _, _ = O.render(scenes.feature_scene(res=(96, 64), rg_shape=(8, 8)), p)
+    assert not np.array_equal(square, cpu)          # the map matters to the picture
+    with pytest.raises(hip.HipError, match="taller than wide"):
+        _dev(scenes.feature_scene(res=(32, 24), rg_shape=(8, 32)))
+
+
 def test_big_mesh_scene_full_stats():
     s = scenes.big_mesh_scene(res=(128, 96))
     p = s.default_params(samples=4, depth=8)

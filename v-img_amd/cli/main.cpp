@@ -24,7 +24,7 @@ static double now_s() {
 
 int main(int argc, char** argv) {
   std::string scene_path, out_path = "v_img_amd.png";
-  int tonemapper = 1, bvh_type = VIMG_BVH_BINNED, px = -1, py = -1;
+  int tonemapper = 0, bvh_type = VIMG_BVH_BINNED, px = -1, py = -1;   // clamp, as src/main.cpp:46
   long spp_override = -1;
   float heatmap_max = -1.f;
   for (int i = 1; i < argc; ++i) {
@@ -32,7 +32,11 @@ int main(int argc, char** argv) {
     auto next = [&]() -> const char* { return (i + 1 < argc) ? argv[++i] : ""; };
     if (a == "-f") scene_path = next();
     else if (a == "-t") next();
-    else if (a == "-c") tonemapper = std::atoi(next());
+    else if (a == "-c") {
+      // an out-of-range value is ignored and the default kept (src/main.cpp:107-112)
+      const int v = std::atoi(next());
+      if (v >= 0 && v < 4) tonemapper = v;
+    }
     else if (a == "-b") bvh_type = std::atoi(next()) == 1 ? VIMG_BVH_SWEEP : VIMG_BVH_BINNED;
     else if (a == "-s") spp_override = std::atol(next());
     else if (a == "-m") heatmap_max = static_cast<float>(std::atof(next()));
@@ -77,7 +81,7 @@ int main(int argc, char** argv) {
   const bool heatmap = heatmap_max >= 0.f && px < 0;
   if (heatmap || params.integrator == VIMG_INTEGRATOR_S_NORMAL ||
       params.integrator == VIMG_INTEGRATOR_G_NORMAL) {
-    if (spp_override <= 0) params.samples = 4;
+    params.samples = 4;   // unconditionally, -s or not: the reference overwrites the sample count here
     tonemapper = 0;
   }
   const int W = view->camera.res_x, H = view->camera.res_y;

@@ -155,11 +155,14 @@ int validate(const VimgScene* sc) {
     const VimgTextureRG& t = sc->rg_textures[i];
     if (t.width == 0 || t.height == 0 || t.wrap_u > 2 || t.wrap_v > 2)
       return fail(VIMG_E_INVALID, "rg texture: bad size or wrap mode");
-    // the reference indexes the +x neighbours with "* height" (quirk Q6); for a non-square map
-    // that reads the wrong texel or runs off the image, so only square maps are accepted
-    if (t.width != t.height)
+    // The reference indexes the +x neighbours with "* height" instead of "* width" (quirk Q6,
+    // include/texture/texture_RG.h:47,52).  For width >= height the largest such index,
+    // (w-1) + (h-1) h, stays inside the w x h array: the WRONG texel is read, reproducibly, and the
+    // kernels and the oracle reproduce it.  For height > width the reference reads beyond its
+    // vector (undefined there): refused.
+    if (t.height > t.width)
       return fail(VIMG_E_UNSUPPORTED,
-                  "non-square metallic-roughness map: the reference reads outside the image there");
+                  "metallic-roughness map taller than wide: the reference reads outside the image there");
     if (t.offset + uint64_t(t.width) * t.height > sc->num_rg_texels)
       return fail(VIMG_E_INVALID, "rg texture out of bounds");
   }
