@@ -543,6 +543,56 @@ def test_mip_chain_and_env_cdfs():
     assert v.lights[v.num_lights - 1].type == abi.LIGHT_BACKGROUND
 
 
+@pytest.mark.parametrize("w,h,wrap_u,wrap_v", [(32, 32, abi.WRAP_REPEAT, abi.WRAP_REPEAT), (40, 24, abi.WRAP_CLAMP, abi.WRAP_MIRROR),
+                                              (17, 64, abi.WRAP_MIRROR, abi.WRAP_CLAMP)])
+def test_mip_chain_is_byte_identical_to_an_independent_restatement(w, h, wrap_u, wrap_v):
+    """The host library's mip chain (and through the byte-exactness tests of test_gpu_parity, the
+    GPU pre-step's) against tests/prestep_ref.py, a numpy restatement of the reference's loop
+    (src/image_texture.cpp:60-158: level count, 8-tap filter, bilinear taps, wrap modes, clamp of
+    negative lobes) - not against the product's own code."""
+    import prestep_ref as R
+    rng = np.random.default_rng(w * 131 + h)
+    img = (rng.random((h, w, 3), dtype=np.float32) * 1.5).astype(np.float32)
+    s = host.HostScene()
+    t = s.add_texture_image(img, wrap_u, wrap_v)
+    s.add_material("lambertian", tex=t)
+    s.add_sphere((0, 0, 0), 1.0, 0)
+    s.build_bvh()
+    v = s.view.contents
+    tex = v.textures[t]
+    want = R.mip_chain(img, wrap_u, wrap_v)
+    assert tex.num_levels == len(want)
+    texels = np.ctypeslib.as_array(v.texels, (v.num_texels, 3))
+    for l, lvl in enumerate(want):
+        lh, lw = lvl.shape[:2]
+        got = texels[tex.level_offset[l]:tex.level_offset[l] + lw * lh].reshape(lh, lw, 3)
+        assert np.array_equal(got.view(np.uint32), lvl.view(np.uint32)), (l, np.abs(got - lvl).max())
+
+
+def test_env_cdfs_are_byte_identical_to_an_independent_restatement():
+    """ArraySampling2D / ArraySampling1D (include/rng/sampling.h:107-197) restated in numpy
+    (tests/prestep_ref.py): running float sums, normalisation by the row integral, sin(pi v) in
+    double - against the host library's tables of an env-map scene."""
+    import prestep_ref as R
+    rng = np.random.default_rng(77)
+    img = (rng.random((24, 48, 3), dtype=np.float32) ** 3 * 20).astype(np.float32)
+    img[5, :, :] = 0          # a row with zero integral: uniform conditional
+    s = host.HostScene()
+    t = s.add_texture_image(img)
+    s.set_background_envmap(t)
+    s.add_material("lambertian", tex=s.add_texture_const((0.5, 0.5, 0.5)))
+    s.add_sphere((0, 0, 0), 1.0, 0)
+    s.build_bvh()
+    v = s.view.contents
+    cdf = np.ctypeslib.as_array(v.cdf_pool, (v.num_cdf,))
+    rows = cdf[v.background.row_cdf_offset:v.background.row_cdf_offset + 25]
+    cols = cdf[v.background.col_cdf_offset:v.background.col_cdf_offset + 24 * 49].reshape(24, 49)
+    want_rows, want_cols = R.env_cdfs(img)
+    assert np.array_equal(cols.view(np.uint32), want_cols.view(np.uint32))
+    assert np.array_equal(rows.view(np.uint32), want_rows.view(np.uint32))
+    assert np.array_equal(cols[5], np.arange(49, dtype=np.float32) / np.float32(48))
+
+
 def test_precompute_hooks_and_8bit_conversions():
     """vimg_host_set_precompute: an installed builder replaces the host loops (and its failure is
     an error, not a silent second path); the 8-bit conversions follow the reference's formulas."""

@@ -297,6 +297,10 @@ StageKernel pick_stage_kernel(const VimgDeviceScene* s, bool deep) {
   return deep ? render_stage_kernel<false, true> : render_stage_kernel<false, false>;
 }
 Pool4Kernel pick_pool4_kernel(const VimgDeviceScene* s, bool deep, int wps) {
+  if (wps <= 2) {
+    if (s->textured) return deep ? render_pool4_kernel<true, true, 2> : render_pool4_kernel<true, false, 2>;
+    return deep ? render_pool4_kernel<false, true, 2> : render_pool4_kernel<false, false, 2>;
+  }
   if (wps <= 3) {
     if (s->textured) return deep ? render_pool4_kernel<true, true, 3> : render_pool4_kernel<true, false, 3>;
     return deep ? render_pool4_kernel<false, true, 3> : render_pool4_kernel<false, false, 3>;
@@ -351,7 +355,7 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   // pool4: three waves per SIMD by policy (config 2: 12.2 Grays/s at three, 11.3 at four; the stand-ins
   // of configs 3 / 4 / 5: 6.6 / 1.56 / 2.62 against 6.1 / 1.15 / 1.52 - a wave's LDS share, i.e. its
   // pool, shrinks faster than the fourth wave pays, most of all under the deep trees' stacks)
-  if (sched == VIMG_SCHED_POOL4) c.wps = (o.waves_per_simd == 4) ? 4 : 3;
+  if (sched == VIMG_SCHED_POOL4) c.wps = (o.waves_per_simd == 4) ? 4 : (o.waves_per_simd == 2 ? 2 : 3);
   RenderArgs& a = c.args;
   a.integrator = p->integrator;
   a.samples = p->samples;
