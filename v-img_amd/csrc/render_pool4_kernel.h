@@ -617,7 +617,10 @@ __device__ __noinline__ void pool4_vertex(uint32_t k_lo, uint32_t k_hi, VIMG_LDS
   }
 }
 
-template <bool TEX, bool DEEP, int WPS>
+// NC: rays a lane walks at the same time (1 or 2).  With two, the box loop tests the node of each
+// in one pass - twice the independent arithmetic and twice the loads in flight per trip, which is
+// what a walk that waits for its node records (LDS on small scenes, L2 / HBM on large ones) lacks.
+template <bool TEX, bool DEEP, int WPS, int NC>
 __global__ void __launch_bounds__(256, WPS)
 render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
   const uint32_t k_lo = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(kargs)),
@@ -650,9 +653,12 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
   VIMG_LDS uint8_t* q_vertex;    // four rings of capacity P: class 0 finishers, 1 Lambertian (+rest), 2 Principled, 3 other
   VIMG_LDS Pool4Wave* pw;
   VIMG_LDS Pool4Diag* dg;
+  VIMG_LDS uint32_t* stack0;   // this lane's stack of its first ray: entry k at stack0[k * 64]; second ray: + stack_entries * 64
   {
     const uint32_t node_bytes = (lds_node_bytes(A.lds_nodes) + 255u) & ~255u;
-    const uint32_t stack_bytes = 4u * A.stack_entries * 64u * 4u;
+    const uint32_t stack_bytes = 4u * uint32_t(NC) * A.stack_entries * 64u * 4u;   // [wave][ray of the lane][entry][lane]
+    stack0 = reinterpret_cast<VIMG_LDS uint32_t*>((VIMG_LDS unsigned char*)lds_raw + node_bytes) +
+             size_t(wave) * NC * A.stack_entries * 64u + lane;
     const uint32_t per_wave = pool4_wave_bytes(P) / 4u;   // in dwords
     VIMG_LDS uint32_t* base =
         reinterpret_cast<VIMG_LDS uint32_t*>((VIMG_LDS unsigned char*)lds_raw + node_bytes + stack_bytes);
@@ -698,22 +704,40 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
   uint32_t idle_polls = 0;
   if (lane == 0) pw->pixels_left = 1u, pw->nan_samples = 0u;
 
-  // ---- persistent walk registers of the lane
-  uint32_t w_slot = SLOT_IDLE, w_phase = 0, w_flags = 0, w_cls = 0;
-  bool w_setup = false, w_any = false, w_found = false, w_exact = false;
-  TravRay ray{f3{0.f, 0.f, 0.f}, f3{0.f, 0.f, 1.f}, 0.0001f, VIMG_INF};
-  f3 w_inv{1.f, 1.f, 1.f};
-  TriRayConst rc{0.f, 0.f, 1.f, 2};
-  float w_dir_len2 = 1.f;
-  uint32_t sp = 0, cur = REF_DONE;
-  HitRec rec;
-  rec.prim = 0xffffffffu;
-  rec.kind = 0;
-  rec.e0 = rec.e1 = rec.e2 = rec.inv_det = 0.f;
+  // ---- persistent walk registers of the lane: NC rays
+  struct WalkCtx {
+    uint32_t slot, phase, flags, cls, sp, cur;
+    bool setup, any, found, exact;
+    TravRay ray;
+    f3 inv;
+    TriRayConst rc;
+    float dir_len2;
+    HitRec rec;
+  };
+  WalkCtx C[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    C[k].slot = SLOT_IDLE, C[k].phase = 0, C[k].flags = 0, C[k].cls = 0, C[k].sp = 0, C[k].cur = REF_DONE;
+    C[k].setup = C[k].any = C[k].found = C[k].exact = false;
+    C[k].ray = TravRay{f3{0.f, 0.f, 0.f}, f3{0.f, 0.f, 1.f}, 0.0001f, VIMG_INF};
+    C[k].inv = f3{1.f, 1.f, 1.f};
+    C[k].rc = TriRayConst{0.f, 0.f, 1.f, 2};
+    C[k].dir_len2 = 1.f;
+    C[k].rec.prim = 0xffffffffu;
+    C[k].rec.kind = 0;
+    C[k].rec.e0 = C[k].rec.e1 = C[k].rec.e2 = C[k].rec.inv_det = 0.f;
+  }
+  const uint32_t kstride = A.stack_entries * 64u;   // dwords between the stacks of a lane's two rays
+  auto count_ctx = [&](auto pred) {
+    uint32_t n = 0;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) n += static_cast<uint32_t>(__popcll(__ballot(pred(C[k]))));
+    return n;
+  };
 
   unsigned long long t_mark = full_stats ? __builtin_readcyclecounter() : 0ull;
   for (;;) {
-    const uint32_t n_walking = __popcll(__ballot(w_slot != SLOT_IDLE));
+    const uint32_t n_walking = count_ctx([](const WalkCtx& c) { return c.slot != SLOT_IDLE; });
     const bool inflight = n_walking != 0u;
     // vertex batches are sorted by the material class of the hit (known from the primitive at the
     // end of the walk), so that a batch executes one material's code: a full batch of any class
@@ -725,7 +749,7 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
     // a vertex batch runs when one is full, or when the walkers starve: no queued ray and
     // pool_starve or more idle lanes (the walk would go on half empty while slots wait here)
     const bool run_vertex = (qv_max >= A.pool_vbatch) ||
-                            (qv_max > 0u && qw_count == 0u && 64u - n_walking >= A.pool_starve);
+                            (qv_max > 0u && qw_count == 0u && 64u * NC - n_walking >= A.pool_starve * NC);
     if (!run_vertex && qw_count == 0u && !inflight) {
       if (!skip_fin || qv_count0 == 0u) break;   // every queue is empty: all done
       skip_fin = false;                          // only waiting slots are left: look at them again
@@ -779,189 +803,230 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
       idle_polls = 0;
 
       for (;;) {
-
-        // (1) idle lanes take queued slots
+        // (1) idle rays of the lanes take queued slots
         {
-          const bool idle = (w_slot == SLOT_IDLE);
-          const unsigned long long mask = __ballot(idle);
-          const uint32_t n_idle = __popcll(mask);
+          unsigned long long m[NC];
+          uint32_t base[NC], n_idle = 0;
+#pragma unroll
+          for (int k = 0; k < NC; ++k) {
+            m[k] = __ballot(C[k].slot == SLOT_IDLE);
+            base[k] = n_idle;
+            n_idle += static_cast<uint32_t>(__popcll(m[k]));
+          }
           const uint32_t take = n_idle < qw_count ? n_idle : qw_count;
           if (take) {
-            const uint32_t r = lane_rank(mask, lane);
-            if (idle && r < take) {
-              w_slot = q_walk[ring(qw_head + r)];
-              w_flags = word(SR_RAY, 3, w_slot);
-              w_phase = (w_flags & SF_HAS_S) ? 0u : 1u;
-              w_setup = true;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+              const uint32_t r = base[k] + lane_rank(m[k], lane);
+              if (C[k].slot == SLOT_IDLE && r < take) {
+                C[k].slot = q_walk[ring(qw_head + r)];
+                C[k].flags = word(SR_RAY, 3, C[k].slot);
+                C[k].phase = (C[k].flags & SF_HAS_S) ? 0u : 1u;
+                C[k].setup = true;
+              }
             }
             qw_head = ring(qw_head + take);
             qw_count -= take;
           }
         }
         // (2) ray set-up (reference include/bvh.h:109-143): everything derived from the ray alone
-        if (__any(w_setup)) {
-          if (w_setup) {
-            const v4u ro = rd(SR_ORIGIN, w_slot);
-            ray.o = f3{uf(ro.x), uf(ro.y), uf(ro.z)};
-            if (w_phase == 0) {
-              const v4u rs = rd(SR_SHADOW, w_slot);
-              ray.d = f3{uf(rs.x), uf(rs.y), uf(rs.z)};
-              ray.max_t = uf(ro.w);
-              w_any = true;
-              cnt.shadow++;
-            } else {
-              const v4u rr = rd(SR_RAY, w_slot);
-              ray.d = f3{uf(rr.x), uf(rr.y), uf(rr.z)};
-              ray.max_t = VIMG_INF;
-              w_any = false;
-              cnt.closest++;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          WalkCtx& c = C[k];
+          if (__any(c.setup)) {
+            if (c.setup) {
+              const v4u ro = rd(SR_ORIGIN, c.slot);
+              c.ray.o = f3{uf(ro.x), uf(ro.y), uf(ro.z)};
+              if (c.phase == 0) {
+                const v4u rs = rd(SR_SHADOW, c.slot);
+                c.ray.d = f3{uf(rs.x), uf(rs.y), uf(rs.z)};
+                c.ray.max_t = uf(ro.w);
+                c.any = true;
+                cnt.shadow++;
+              } else {
+                const v4u rr = rd(SR_RAY, c.slot);
+                c.ray.d = f3{uf(rr.x), uf(rr.y), uf(rr.z)};
+                c.ray.max_t = VIMG_INF;
+                c.any = false;
+                cnt.closest++;
+              }
+              c.inv = f3{1.0f / c.ray.d.x, 1.0f / c.ray.d.y, 1.0f / c.ray.d.z};
+              c.exact = (c.ray.d.x == 0.f) || (c.ray.d.y == 0.f) || (c.ray.d.z == 0.f);
+              c.rc = tri_ray_const(c.ray.d);
+              c.dir_len2 = dot(c.ray.d, c.ray.d);
+              const float root =
+                  slab(load3k(g.root_min), load3k(g.root_max), c.ray.o, c.inv, c.ray.min_t, c.ray.max_t);
+              c.cur = is_inf(root) ? REF_DONE : g.root_ref;
+              c.sp = 0;
+              c.found = false;
+              c.rec.prim = 0xffffffffu;
+              c.setup = false;
             }
-            w_inv = f3{1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z};
-            w_exact = (ray.d.x == 0.f) || (ray.d.y == 0.f) || (ray.d.z == 0.f);
-            rc = tri_ray_const(ray.d);
-            w_dir_len2 = dot(ray.d, ray.d);
-            const float root =
-                slab(load3k(g.root_min), load3k(g.root_max), ray.o, w_inv, ray.min_t, ray.max_t);
-            cur = is_inf(root) ? REF_DONE : g.root_ref;
-            sp = 0;
-            w_found = false;
-            rec.prim = 0xffffffffu;
-            w_setup = false;
           }
         }
 
-        if (!__any(w_slot != SLOT_IDLE)) break;
-        // (3) walk until a quarter of the wave has a finished ray (or nothing is left to walk)
+        if (count_ctx([](const WalkCtx& c) { return c.slot != SLOT_IDLE; }) == 0u) break;
+        // (3) walk until a quarter of the rays in flight have finished (or nothing is left to walk)
         for (;;) {
           // the box loop in two builds: rays with a zero direction component need the exact
           // select form of the slab test (0 * inf); a round without such a ray runs the build
-          // that has only the min/max form
+          // that has only the min/max form.  One pass of the loop steps every ray of the lane that
+          // stands at an internal node; the step is branch-free (selects), so the passes of a
+          // lane's rays interleave in the instruction stream.
           auto box_loop = [&](auto exact_possible) {
-          while (cur != REF_DONE && ref_count(cur) == 0) {
-            v4f na, nb, nc;
-            v2u refs;
-            if (!DEEP || cur < L.n_nodes) {   // the build for trees that fit has every node in LDS
-              na = L.na[cur], nb = L.nb[cur], nc = L.nc[cur];
-              refs = L.nm[cur];
-            } else {
-              gptr<DNode> nd = g.nodes + cur;
-              na = nd->a, nb = nd->b, nc = nd->c;
-              refs = v2u{nd->left_ref, nd->right_ref};
+            for (;;) {
+              bool act[NC];
+              bool any_act = false;
+#pragma unroll
+              for (int k = 0; k < NC; ++k) {
+                act[k] = C[k].cur != REF_DONE && ref_count(C[k].cur) == 0;
+                any_act = any_act || act[k];
+              }
+              if (!__any(any_act)) break;
+              v4f na[NC], nb[NC], nc[NC];
+              v2u refs[NC];
+              uint32_t popped[NC], sp_below[NC];
+#pragma unroll
+              for (int k = 0; k < NC; ++k) {
+                const uint32_t at = act[k] ? C[k].cur : 0u;   // (a ray that does not step reads node 0 and drops it)
+                if (!DEEP || at < L.n_nodes) {   // the build for trees that fit has every node in LDS
+                  na[k] = L.na[at], nb[k] = L.nb[at], nc[k] = L.nc[at];
+                  refs[k] = L.nm[at];
+                } else {
+                  gptr<DNode> nd = g.nodes + at;
+                  na[k] = nd->a, nb[k] = nd->b, nc[k] = nd->c;
+                  refs[k] = v2u{nd->left_ref, nd->right_ref};
+                }
+                sp_below[k] = C[k].sp != 0 ? C[k].sp - 1 : 0u;
+                popped[k] = stack0[k * kstride + sp_below[k] * 64];
+              }
+#pragma unroll
+              for (int k = 0; k < NC; ++k) {
+                WalkCtx& c = C[k];
+                cnt.internal += act[k] ? stat_inc : 0u;
+                float h1, h2;
+                if (decltype(exact_possible)::value && c.exact) {
+                  h1 = slab(f3{na[k].x, na[k].y, na[k].z}, f3{na[k].w, nb[k].x, nb[k].y}, c.ray.o, c.inv, c.ray.min_t, c.ray.max_t);
+                  h2 = slab(f3{nb[k].z, nb[k].w, nc[k].x}, f3{nc[k].y, nc[k].z, nc[k].w}, c.ray.o, c.inv, c.ray.min_t, c.ray.max_t);
+                } else {
+                  h1 = slab_fast(f3{na[k].x, na[k].y, na[k].z}, f3{na[k].w, nb[k].x, nb[k].y}, c.ray.o, c.inv, c.ray.min_t, c.ray.max_t);
+                  h2 = slab_fast(f3{nb[k].z, nb[k].w, nc[k].x}, f3{nc[k].y, nc[k].z, nc[k].w}, c.ray.o, c.inv, c.ray.min_t, c.ray.max_t);
+                }
+                const bool in1 = !is_inf(h1), in2 = !is_inf(h2);
+                const uint32_t c1 = refs[k].x, c2 = refs[k].y;
+                // branch-free step: the entry a pop would return was read before the box test (its
+                // latency hides behind the test); the far child is written above the top of the
+                // stack whether it is kept or not (the slot is free), and sp moves by select
+                const bool both = in1 && in2, any = in1 || in2;
+                const bool first_is_near = c.any ? false : (h2 > h1);
+                const uint32_t near_c = first_is_near ? c1 : c2;
+                const uint32_t far_c = first_is_near ? c2 : c1;
+                stack0[k * kstride + c.sp * 64] = far_c;
+                const uint32_t one_c = in1 ? c1 : c2;
+                const uint32_t next_cur = both ? near_c : (any ? one_c : (c.sp != 0 ? popped[k] : REF_DONE));
+                const uint32_t next_sp = both ? c.sp + 1 : (any ? c.sp : sp_below[k]);
+                c.cur = act[k] ? next_cur : c.cur;
+                c.sp = act[k] ? next_sp : c.sp;
+              }
+              // deep trees: when only a few rays still descend, the ones that wait at a leaf go first
+              // (the box loop of the config-5 stand-in ran with 27 % of its lanes busy)
+              if constexpr (DEEP) {
+                if (count_ctx([](const WalkCtx& c) { return c.cur != REF_DONE && ref_count(c.cur) == 0; }) < box_min * NC) break;
+              }
             }
-            const uint32_t sp_below = sp != 0 ? sp - 1 : 0u;
-            const uint32_t popped = L.stack[sp_below * 64];
-            cnt.internal += stat_inc;
-            float h1, h2;
-            if (decltype(exact_possible)::value && w_exact) {
-              h1 = slab(f3{na.x, na.y, na.z}, f3{na.w, nb.x, nb.y}, ray.o, w_inv, ray.min_t, ray.max_t);
-              h2 = slab(f3{nb.z, nb.w, nc.x}, f3{nc.y, nc.z, nc.w}, ray.o, w_inv, ray.min_t, ray.max_t);
-            } else {
-              h1 = slab_fast(f3{na.x, na.y, na.z}, f3{na.w, nb.x, nb.y}, ray.o, w_inv, ray.min_t, ray.max_t);
-              h2 = slab_fast(f3{nb.z, nb.w, nc.x}, f3{nc.y, nc.z, nc.w}, ray.o, w_inv, ray.min_t, ray.max_t);
-            }
-            const bool in1 = !is_inf(h1), in2 = !is_inf(h2);
-            const uint32_t c1 = refs.x, c2 = refs.y;
-            // branch-free step: the entry a pop would return was read before the box test (its
-            // latency hides behind the test); the far child is written above the top of the stack
-            // whether it is kept or not (the slot is free), and sp moves by select
-            const bool both = in1 && in2, any = in1 || in2;
-            const bool first_is_near = w_any ? false : (h2 > h1);
-            const uint32_t near_c = first_is_near ? c1 : c2;
-            const uint32_t far_c = first_is_near ? c2 : c1;
-            L.stack[sp * 64] = far_c;
-            const uint32_t one_c = in1 ? c1 : c2;
-            cur = both ? near_c : (any ? one_c : (sp != 0 ? popped : REF_DONE));
-            sp = both ? sp + 1 : (any ? sp : sp_below);
-            // deep trees: when only a few lanes still descend, the lanes that wait at a leaf go
-            // first (the box loop of the config-5 stand-in ran with 27 % of its lanes busy)
-            if constexpr (DEEP) {
-              if (__popcll(__ballot(cur != REF_DONE && ref_count(cur) == 0)) < box_min) break;
-            }
-          }
           };
-          if (__any(w_exact && w_slot != SLOT_IDLE))
+          bool exact_any = false;
+#pragma unroll
+          for (int k = 0; k < NC; ++k) exact_any = exact_any || (C[k].exact && C[k].slot != SLOT_IDLE);
+          if (__any(exact_any))
             box_loop(std::true_type{});
           else
             box_loop(std::false_type{});
 
-          if (cur != REF_DONE && (!DEEP || ref_count(cur) != 0)) {
-            const uint32_t first = ref_index(cur), count = ref_count(cur);
-            cnt.leaf += stat_inc;
-            bool stop = false;
-            for (uint32_t i = 0; i < count && !stop; ++i) {
-              gptr<DLeafPrim> lp = g.leaf_prims + (first + i);
-              v4f a, b, c;
-              if (leaf_in_lds) {
-                const VIMG_LDS v4f* ll = lds_leaf + (first + i) * 3u;
-                a = ll[0], b = ll[1], c = ll[2];
-              } else {
-                a = lp->a, b = lp->b;
-                c = reinterpret_cast<gptr<v4f>>(lp)[2];
+#pragma unroll
+          for (int k = 0; k < NC; ++k) {
+            WalkCtx& c = C[k];
+            if (c.cur != REF_DONE && (!DEEP || ref_count(c.cur) != 0)) {
+              const uint32_t first = ref_index(c.cur), count = ref_count(c.cur);
+              cnt.leaf += stat_inc;
+              bool stop = false;
+              for (uint32_t i = 0; i < count && !stop; ++i) {
+                gptr<DLeafPrim> lp = g.leaf_prims + (first + i);
+                v4f a, b, cc;
+                if (leaf_in_lds) {
+                  const VIMG_LDS v4f* ll = lds_leaf + (first + i) * 3u;
+                  a = ll[0], b = ll[1], cc = ll[2];
+                } else {
+                  a = lp->a, b = lp->b;
+                  cc = reinterpret_cast<gptr<v4f>>(lp)[2];
+                }
+                const float c0 = cc.x;
+                const uint32_t lp_prim = __float_as_uint(cc.y), kind = __float_as_uint(cc.z),
+                               lp_cls = __float_as_uint(cc.w);   // DLeafPrim: c0 | prim | kind | cls
+                cnt.prim += stat_inc;
+                bool hit = false;
+                float t = 0.f, e0 = 0.f, e1 = 0.f, e2 = 0.f, idet = 0.f;
+                if (kind == 0) {
+                  hit = tri_test_flat(f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c0}, c.ray, c.rc, t, e0,
+                                      e1, e2, idet);
+                } else if (kind == 1) {
+                  cnt.sphere += stat_inc;
+                  hit = sphere_test(f3{a.x, a.y, a.z}, a.w, c.ray, c.dir_len2, t);
+                }
+                // by select: a hit shortens the ray; an any-hit ray stops at its first hit, a
+                // closest-hit ray keeps the record of the last success
+                c.ray.max_t = hit ? t : c.ray.max_t;
+                c.found = c.found || hit;
+                stop = hit && c.any;
+                const bool keep_rec = hit && !c.any;
+                c.rec.e0 = keep_rec ? e0 : c.rec.e0, c.rec.e1 = keep_rec ? e1 : c.rec.e1;
+                c.rec.e2 = keep_rec ? e2 : c.rec.e2, c.rec.inv_det = keep_rec ? idet : c.rec.inv_det;
+                c.rec.prim = keep_rec ? lp_prim : c.rec.prim;
+                c.rec.kind = keep_rec ? kind : c.rec.kind;
+                c.cls = keep_rec ? lp_cls : c.cls;
               }
-              const float c0 = c.x;
-              const uint32_t lp_prim = __float_as_uint(c.y), kind = __float_as_uint(c.z),
-                             lp_cls = __float_as_uint(c.w);   // DLeafPrim: c0 | prim | kind | cls
-              cnt.prim += stat_inc;
-              bool hit = false;
-              float t = 0.f, e0 = 0.f, e1 = 0.f, e2 = 0.f, idet = 0.f;
-              if (kind == 0) {
-                hit = tri_test_flat(f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c0}, ray, rc, t, e0,
-                                    e1, e2, idet);
-              } else if (kind == 1) {
-                cnt.sphere += stat_inc;
-                hit = sphere_test(f3{a.x, a.y, a.z}, a.w, ray, w_dir_len2, t);
-              }
-              // by select: a hit shortens the ray; an any-hit ray stops at its first hit, a
-              // closest-hit ray keeps the record of the last success
-              ray.max_t = hit ? t : ray.max_t;
-              w_found = w_found || hit;
-              stop = hit && w_any;
-              const bool keep_rec = hit && !w_any;
-              rec.e0 = keep_rec ? e0 : rec.e0, rec.e1 = keep_rec ? e1 : rec.e1;
-              rec.e2 = keep_rec ? e2 : rec.e2, rec.inv_det = keep_rec ? idet : rec.inv_det;
-              rec.prim = keep_rec ? lp_prim : rec.prim;
-              rec.kind = keep_rec ? kind : rec.kind;
-              w_cls = keep_rec ? lp_cls : w_cls;
+              const uint32_t sp_below = c.sp != 0 ? c.sp - 1 : 0u;
+              const uint32_t popped = stack0[k * kstride + sp_below * 64];
+              c.cur = (stop || c.sp == 0) ? REF_DONE : popped;
+              c.sp = sp_below;
             }
-            const uint32_t sp_below = sp != 0 ? sp - 1 : 0u;
-            const uint32_t popped = L.stack[sp_below * 64];
-            cur = (stop || sp == 0) ? REF_DONE : popped;
-            sp = sp_below;
           }
 
-          const uint32_t n_fin = __popcll(__ballot(w_slot != SLOT_IDLE && cur == REF_DONE));
-          const uint32_t n_act = __popcll(__ballot(w_slot != SLOT_IDLE && cur != REF_DONE));
-          if (n_act == 0 || n_fin >= A.pool_refill) break;
+          const uint32_t n_fin = count_ctx([](const WalkCtx& c) { return c.slot != SLOT_IDLE && c.cur == REF_DONE; });
+          const uint32_t n_act = count_ctx([](const WalkCtx& c) { return c.slot != SLOT_IDLE && c.cur != REF_DONE; });
+          if (n_act == 0 || n_fin >= A.pool_refill * NC) break;
         }
         // (4) retire finished rays: second ray of the item, or hand the slot to the vertex stage
-        bool done_item = false;
-        if (w_slot != SLOT_IDLE && cur == REF_DONE) {
-          if (w_phase == 0) {
-            if (w_found) w_flags |= SF_OCCLUDED;
-            if (w_flags & SF_HAS_R) {
-              w_phase = 1;
-              w_setup = true;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          WalkCtx& c = C[k];
+          bool done_item = false;
+          if (c.slot != SLOT_IDLE && c.cur == REF_DONE) {
+            if (c.phase == 0) {
+              if (c.found) c.flags |= SF_OCCLUDED;
+              if (c.flags & SF_HAS_R) {
+                c.phase = 1;
+                c.setup = true;
+              } else {
+                done_item = true;
+              }
             } else {
+              if (c.found) {
+                c.flags |= SF_FOUND | (c.rec.kind == 1 ? SF_KIND_SPHERE : 0u);
+                wr(SR_SHADOW, c.slot, v4u{fu(c.rec.e0), fu(c.rec.e1), fu(c.rec.e2), fu(c.rec.inv_det)});
+                q_prim[c.slot] = c.rec.prim;
+                word(SR_ORIGIN, 3, c.slot) = fu(c.ray.max_t);
+              }
               done_item = true;
             }
-          } else {
-            if (w_found) {
-              w_flags |= SF_FOUND | (rec.kind == 1 ? SF_KIND_SPHERE : 0u);
-              wr(SR_SHADOW, w_slot, v4u{fu(rec.e0), fu(rec.e1), fu(rec.e2), fu(rec.inv_det)});
-              q_prim[w_slot] = rec.prim;
-              word(SR_ORIGIN, 3, w_slot) = fu(ray.max_t);
-            }
-            done_item = true;
+            if (done_item) word(SR_RAY, 3, c.slot) = c.flags;
           }
-          if (done_item) word(SR_RAY, 3, w_slot) = w_flags;
-        }
-        {
           // class of the batch this slot joins: 0 = its path ends (miss, no path ray, emitter hit under
           // mis, any hit under the normal integrators), else the material class of the vertex
           // (leaf record: 0 emitter, 1 Lambertian, 2 Principled, 3 other)
           uint32_t cls = 0;
-          if (done_item && (w_flags & SF_FOUND) && A.integrator >= VIMG_INTEGRATOR_MATERIAL) {
-            cls = w_cls;
+          if (done_item && (c.flags & SF_FOUND) && A.integrator >= VIMG_INTEGRATOR_MATERIAL) {
+            cls = c.cls;
             if (cls == 0 && material_mode) cls = 3;   // material_integrator shades emitters too
             if (cls != 0) {
               if (A.pool_classes == 1) cls = 1;
@@ -973,12 +1038,12 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
                                    m2 = __ballot(done_item && cls == 2),
                                    m3 = __ballot(done_item && cls == 3);
           if (done_item) {
-            const uint8_t id = static_cast<uint8_t>(w_slot);
+            const uint8_t id = static_cast<uint8_t>(c.slot);
             if (cls == 0) q_vertex[ring(qv_head0 + qv_count0 + lane_rank(m0, lane))] = id;
             else if (cls == 1) q_vertex[P + ring(qv_head1 + qv_count1 + lane_rank(m1, lane))] = id;
             else if (cls == 2) q_vertex[2 * P + ring(qv_head2 + qv_count2 + lane_rank(m2, lane))] = id;
             else q_vertex[3 * P + ring(qv_head3 + qv_count3 + lane_rank(m3, lane))] = id;
-            w_slot = SLOT_IDLE;
+            c.slot = SLOT_IDLE;
           }
           qv_count0 += __popcll(m0);
           qv_count1 += __popcll(m1);
@@ -991,9 +1056,9 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
             qv_count3 >= A.pool_vbatch)
           break;
         if (qw_count == 0u) {
-          const uint32_t walking = __popcll(__ballot(w_slot != SLOT_IDLE));
+          const uint32_t walking = count_ctx([](const WalkCtx& c) { return c.slot != SLOT_IDLE; });
           if (walking == 0u) break;
-          if (64u - walking >= A.pool_starve && (qv_count0 | qv_count1 | qv_count2 | qv_count3) != 0u) break;
+          if (64u * NC - walking >= A.pool_starve * NC && (qv_count0 | qv_count1 | qv_count2 | qv_count3) != 0u) break;
         }
       }
     }

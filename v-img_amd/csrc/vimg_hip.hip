@@ -239,7 +239,8 @@ void options_from_env(VimgHipOptions* o) {
       {"VIMG_HIP_POOL_CLASSES", &o->pool_classes},     {"VIMG_HIP_POOL_STARVE", &o->pool_starve},
       {"VIMG_HIP_POOL_BOXMIN", &o->pool_boxmin},       {"VIMG_HIP_LDS_LEAF", &o->lds_leaf},
       {"VIMG_HIP_STAGE_SLOTS", &o->stage_slots},       {"VIMG_HIP_STAGE_SEG_LEN", &o->stage_seg_len},
-      {"VIMG_HIP_STAGE_WCHUNK", &o->stage_wchunk},     {"VIMG_HIP_STAGE_WALK_QUOTA", &o->stage_walk_quota}};
+      {"VIMG_HIP_STAGE_WCHUNK", &o->stage_wchunk},     {"VIMG_HIP_STAGE_WALK_QUOTA", &o->stage_walk_quota},
+      {"VIMG_HIP_POOL4_RAYS", &o->pool4_rays}};
   for (auto& v : vars)
     if (const char* e = getenv(v.name)) *v.field = atoi(e);
 }
@@ -273,13 +274,14 @@ struct LaunchCfg {
   int sched;     // VIMG_SCHED_* of this launch
   bool pooled;   // render_pool_kernel for this launch
   int wps;       // register-budget build (waves per SIMD of __launch_bounds__)
+  int rays;      // pool4: rays a lane walks at the same time (1 or 2)
   bool deep;     // pooled / staged kernel: build whose box loop yields to waiting leaves (tree beyond the LDS node cache)
 };
 
 using RenderKernel = void (*)(const DScene, const RenderArgs, float*, DeviceStats*, unsigned int*);
 using StageKernel = void (*)(const StageKArgs*);
 using Pool4Kernel = void (*)(const Pool4KArgs*);
-Pool4Kernel pick_pool4_kernel(const VimgDeviceScene* s, bool deep, int wps);
+Pool4Kernel pick_pool4_kernel(const VimgDeviceScene* s, bool deep, int wps, int rays);
 RenderKernel pick_kernel(const VimgDeviceScene* s, bool pooled, int wps, bool deep) {
   if (pooled) {
     if (deep) {
@@ -296,21 +298,23 @@ StageKernel pick_stage_kernel(const VimgDeviceScene* s, bool deep) {
   if (s->textured) return deep ? render_stage_kernel<true, true> : render_stage_kernel<true, false>;
   return deep ? render_stage_kernel<false, true> : render_stage_kernel<false, false>;
 }
-Pool4Kernel pick_pool4_kernel(const VimgDeviceScene* s, bool deep, int wps) {
-  if (wps <= 2) {
-    if (s->textured) return deep ? render_pool4_kernel<true, true, 2> : render_pool4_kernel<true, false, 2>;
-    return deep ? render_pool4_kernel<false, true, 2> : render_pool4_kernel<false, false, 2>;
-  }
-  if (wps <= 3) {
-    if (s->textured) return deep ? render_pool4_kernel<true, true, 3> : render_pool4_kernel<true, false, 3>;
-    return deep ? render_pool4_kernel<false, true, 3> : render_pool4_kernel<false, false, 3>;
-  }
-  if (s->textured) return deep ? render_pool4_kernel<true, true, 4> : render_pool4_kernel<true, false, 4>;
-  return deep ? render_pool4_kernel<false, true, 4> : render_pool4_kernel<false, false, 4>;
+template <int WPS, int NC>
+Pool4Kernel pool4_build(bool tex, bool deep) {
+  if (tex) return deep ? render_pool4_kernel<true, true, WPS, NC> : render_pool4_kernel<true, false, WPS, NC>;
+  return deep ? render_pool4_kernel<false, true, WPS, NC> : render_pool4_kernel<false, false, WPS, NC>;
+}
+// (two rays per lane - NC = 2, both stepped in one pass of the box loop - measured slower and is not
+// built: config 2 9.3 against 11.7 Grays/s at 64 spp, 228 B of scratch; the loop runs until the
+// last of 128 rays instead of 64 has reached a leaf, which costs more lanes than the interleaving
+// hides latency)
+Pool4Kernel pick_pool4_kernel(const VimgDeviceScene* s, bool deep, int wps, int rays) {
+  (void)rays;
+  if (wps >= 4) return pool4_build<4, 1>(s->textured, deep);
+  return pool4_build<3, 1>(s->textured, deep);
 }
 const void* kernel_of(const VimgDeviceScene* s, const LaunchCfg& c) {
   if (c.sched == VIMG_SCHED_STAGE) return reinterpret_cast<const void*>(pick_stage_kernel(s, c.deep));
-  if (c.sched == VIMG_SCHED_POOL4) return reinterpret_cast<const void*>(pick_pool4_kernel(s, c.deep, c.wps));
+  if (c.sched == VIMG_SCHED_POOL4) return reinterpret_cast<const void*>(pick_pool4_kernel(s, c.deep, c.wps, c.rays));
   return reinterpret_cast<const void*>(pick_kernel(s, c.pooled, c.wps, c.deep));
 }
 
@@ -355,7 +359,8 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   // pool4: three waves per SIMD by policy (config 2: 12.2 Grays/s at three, 11.3 at four; the stand-ins
   // of configs 3 / 4 / 5: 6.6 / 1.56 / 2.62 against 6.1 / 1.15 / 1.52 - a wave's LDS share, i.e. its
   // pool, shrinks faster than the fourth wave pays, most of all under the deep trees' stacks)
-  if (sched == VIMG_SCHED_POOL4) c.wps = (o.waves_per_simd == 4) ? 4 : (o.waves_per_simd == 2 ? 2 : 3);
+  if (sched == VIMG_SCHED_POOL4) c.wps = (o.waves_per_simd == 4) ? 4 : 3;
+  c.rays = 1;
   RenderArgs& a = c.args;
   a.integrator = p->integrator;
   a.samples = p->samples;
@@ -371,7 +376,7 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   a.single_y = sy;
   // LDS budget per 256-thread workgroup: stacks first, then as much of the top of the tree as
   // fits in 40 KiB total (keeps >= 4 workgroups per CU inside the 160 KiB)
-  const uint32_t stack_bytes = 4u * a.stack_entries * 64u * 4u;
+  const uint32_t stack_bytes = 4u * a.stack_entries * 64u * 4u * uint32_t(c.rays);
   // (the pooled and staged kernels spend LDS on path slots / queue chunks instead: they keep the
   // first six levels of the tree, 4 KiB - config 5: 40 KiB budget 1.69, 28 KiB 1.78 Grays/s)
   uint32_t budget = (sched != VIMG_SCHED_LANE) ? std::min(40u * 1024u, stack_bytes + 4608u) : 40u * 1024u;
@@ -589,7 +594,7 @@ int enqueue_render(VimgDeviceScene* s, const VimgRenderParams* p, float* d_out, 
     Pool4KArgs* blk = static_cast<Pool4KArgs*>(s->d_stage_kargs);
     hipLaunchKernelGGL(pool4_args_kernel, dim3(1), dim3(64), 0, st, Pool4KArgs{s->d, c.args, d_out, stats, s->d_counter}, blk);
     if (ev0) HIP_TRY(hipEventRecord(ev0, st));
-    hipLaunchKernelGGL(pick_pool4_kernel(s, c.deep, c.wps), dim3(c.grid), dim3(256), c.lds_bytes, st,
+    hipLaunchKernelGGL(pick_pool4_kernel(s, c.deep, c.wps, c.rays), dim3(c.grid), dim3(256), c.lds_bytes, st,
                        static_cast<const Pool4KArgs*>(blk));
   } else
     hipLaunchKernelGGL(pick_kernel(s, c.pooled, c.wps, c.deep), dim3(c.grid), dim3(256), c.lds_bytes, st, s->d, c.args,
@@ -959,7 +964,7 @@ const char* vimg_hip_launch_kernel(const VimgDeviceScene* s, const VimgRenderPar
   if (p->tile_world == 0 || p->tile_rank >= p->tile_world) return "";
   const LaunchCfg c = make_launch(s, p, -1, -1);
   static const char* pool4_names[2][2] = {{"render_pool4_kernel<false>", "render_pool4_kernel<false,deep>"},
-                                          {"render_pool4_kernel<true>", "render_pool4_kernel<true,deep>"}};
+                                          {"render_pool4_kernel<true>", "render_pool4_kernel<true,deep>"}};   // (+ waves per SIMD, rays per lane)
   if (c.sched == VIMG_SCHED_STAGE) return stage_names[s->textured ? 1 : 0][c.deep ? 1 : 0];
   if (c.sched == VIMG_SCHED_POOL4) return pool4_names[s->textured ? 1 : 0][c.deep ? 1 : 0];
   if (c.deep) return deep_names[s->textured ? 1 : 0][c.wps >= 3 ? 1 : 0];
