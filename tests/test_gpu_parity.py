@@ -808,9 +808,11 @@ def test_heatmap_matches_oracle_bit_for_bit(scene_name, bvh):
 
 
 # ------------------------------------------------------------------ GPU BVH builder (8f rank 4)
+@pytest.mark.parametrize("builder", ["lbvh", "ploc"])
 @pytest.mark.parametrize("name", ["one sphere", "two prims", "disney_spheres", "big_mesh", "config4"])
-def test_lbvh_builder_gives_a_valid_tree_and_the_same_picture(name):
-    """vimg_hip_build_lbvh: Morton order + radix tree + bottom-up boxes on the GPU, emitted in the
+def test_gpu_builders_give_a_valid_tree_and_the_same_picture(name, builder):
+    """vimg_hip_build_lbvh (Morton order + radix tree + bottom-up boxes, one primitive per leaf) and
+    vimg_hip_build_ploc (locally-ordered clustering + SAH leaves of up to 8), emitted in the
     reference's BVH layout.  The tree must satisfy the layout's invariants; GPU kernels and oracle
     then walk the same tree, so their images are bit-identical as with the host-built trees; and
     the picture does not depend on which tree was built (ties aside)."""
@@ -834,13 +836,15 @@ def test_lbvh_builder_gives_a_valid_tree_and_the_same_picture(name):
         s = scenes.config4_scene(res=(96, 54), n_lat=48, env=(128, 64))
     p = s.default_params(samples=4)
     sah_img, _ = _dev(s).render_to_host(p)
-    s.build_bvh_with(hip.lbvh_builder())
-    depth = _check_tree(s, leaf_max=1)
+    s.build_bvh_with(hip.lbvh_builder() if builder == "lbvh" else hip.ploc_builder())
+    depth = _check_tree(s, leaf_max=1 if builder == "lbvh" else 8)
     n = s.view.contents.num_prims
-    assert s.view.contents.bvh.num_nodes == 2 * n - 1 and depth <= 64
+    if builder == "lbvh":
+        assert s.view.contents.bvh.num_nodes == 2 * n - 1
+    assert s.view.contents.bvh.num_nodes <= 2 * n - 1 and depth <= 64
     cpu, cst, _ = O.render(s, p)
     gpu, gst = _dev(s).render_to_host(p)
-    _compare_images(gpu, cpu, name + " (LBVH)", min_exact=0.995)
+    _compare_images(gpu, cpu, f"{name} ({builder})", min_exact=0.995)
     assert gst.paths == cst.paths and abs(gst.rays - cst.rays) <= max(8, 2e-3 * cst.rays)
     same = (gpu.view(np.uint32) == sah_img.view(np.uint32)).all(axis=-1).mean()
     assert same > 0.97 and abs(gpu.mean() - sah_img.mean()) <= 0.03 * abs(sah_img.mean()) + 1e-6

@@ -11,10 +11,12 @@ spp = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 s = scenes.config5_scene()
 p = s.default_params(samples=spp, depth=2 ** 32 - 1)
 out = {}
-for name in ("sweep SAH (host)", "LBVH (GPU)"):
+for name in ("sweep SAH (host)", "LBVH (GPU)", "PLOC (GPU)"):
     t0 = time.perf_counter()
     if name.startswith("LBVH"):
         s.build_bvh_with(hip.lbvh_builder())
+    elif name.startswith("PLOC"):
+        s.build_bvh_with(hip.ploc_builder())
     else:
         s.build_bvh(abi.BVH_SWEEP)
     t_build = time.perf_counter() - t0

@@ -215,6 +215,8 @@ HIP_SYMBOLS = {
     "vimg_hip_rgb8_to_normal": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint64, f32, Pf32]),
     "vimg_hip_build_lbvh": (C.c_int, [u32, Pf32, C.POINTER(u32), C.POINTER(u32), C.c_void_p, Pf32,
                                      C.POINTER(u32)]),
+    "vimg_hip_build_ploc": (C.c_int, [u32, Pf32, C.POINTER(u32), C.POINTER(u32), C.c_void_p, Pf32,
+                                     C.POINTER(u32)]),
     "vimg_hip_scene_bytes": (i64, [C.c_void_p]),
     "vimg_hip_scene_kernel": (C.c_char_p, [C.c_void_p]),
     "vimg_hip_launch_kernel": (C.c_char_p, [C.c_void_p, PParams]),

@@ -278,3 +278,8 @@ def install_gpu_precompute(enable=True):
 def lbvh_builder():
     """Function pointer of the GPU LBVH builder for HostScene.build_bvh_with()."""
     return C.cast(abi.hip_lib().vimg_hip_build_lbvh, C.c_void_p)
+
+
+def ploc_builder():
+    """Function pointer of the GPU PLOC + SAH-leaf builder for HostScene.build_bvh_with()."""
+    return C.cast(abi.hip_lib().vimg_hip_build_ploc, C.c_void_p)
