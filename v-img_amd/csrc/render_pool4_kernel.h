@@ -883,50 +883,47 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
                 any_act = any_act || act[k];
               }
               if (!__any(any_act)) break;
-              v4f na[NC], nb[NC], nc[NC];
-              v2u refs[NC];
-              uint32_t popped[NC], sp_below[NC];
-#pragma unroll
-              for (int k = 0; k < NC; ++k) {
-                const uint32_t at = act[k] ? C[k].cur : 0u;   // (a ray that does not step reads node 0 and drops it)
-                if (!DEEP || at < L.n_nodes) {   // the build for trees that fit has every node in LDS
-                  na[k] = L.na[at], nb[k] = L.nb[at], nc[k] = L.nc[at];
-                  refs[k] = L.nm[at];
-                } else {
-                  gptr<DNode> nd = g.nodes + at;
-                  na[k] = nd->a, nb[k] = nd->b, nc[k] = nd->c;
-                  refs[k] = v2u{nd->left_ref, nd->right_ref};
-                }
-                sp_below[k] = C[k].sp != 0 ? C[k].sp - 1 : 0u;
-                popped[k] = stack0[k * kstride + sp_below[k] * 64];
-              }
 #pragma unroll
               for (int k = 0; k < NC; ++k) {
                 WalkCtx& c = C[k];
-                cnt.internal += act[k] ? stat_inc : 0u;
-                float h1, h2;
-                if (decltype(exact_possible)::value && c.exact) {
-                  h1 = slab(f3{na[k].x, na[k].y, na[k].z}, f3{na[k].w, nb[k].x, nb[k].y}, c.ray.o, c.inv, c.ray.min_t, c.ray.max_t);
-                  h2 = slab(f3{nb[k].z, nb[k].w, nc[k].x}, f3{nc[k].y, nc[k].z, nc[k].w}, c.ray.o, c.inv, c.ray.min_t, c.ray.max_t);
-                } else {
-                  h1 = slab_fast(f3{na[k].x, na[k].y, na[k].z}, f3{na[k].w, nb[k].x, nb[k].y}, c.ray.o, c.inv, c.ray.min_t, c.ray.max_t);
-                  h2 = slab_fast(f3{nb[k].z, nb[k].w, nc[k].x}, f3{nc[k].y, nc[k].z, nc[k].w}, c.ray.o, c.inv, c.ray.min_t, c.ray.max_t);
+                // (the step runs under the lanes' execution mask: a lane whose ray does not stand at
+                // an internal node issues nothing, so the VALU lane counters keep meaning work done)
+                if (act[k]) {
+                  v4f na, nb, nc;
+                  v2u refs;
+                  if (!DEEP || c.cur < L.n_nodes) {   // the build for trees that fit has every node in LDS
+                    na = L.na[c.cur], nb = L.nb[c.cur], nc = L.nc[c.cur];
+                    refs = L.nm[c.cur];
+                  } else {
+                    gptr<DNode> nd = g.nodes + c.cur;
+                    na = nd->a, nb = nd->b, nc = nd->c;
+                    refs = v2u{nd->left_ref, nd->right_ref};
+                  }
+                  const uint32_t sp_below = c.sp != 0 ? c.sp - 1 : 0u;
+                  const uint32_t popped = stack0[k * kstride + sp_below * 64];
+                  cnt.internal += stat_inc;
+                  float h1, h2;
+                  if (decltype(exact_possible)::value && c.exact) {
+                    h1 = slab(f3{na.x, na.y, na.z}, f3{na.w, nb.x, nb.y}, c.ray.o, c.inv, c.ray.min_t, c.ray.max_t);
+                    h2 = slab(f3{nb.z, nb.w, nc.x}, f3{nc.y, nc.z, nc.w}, c.ray.o, c.inv, c.ray.min_t, c.ray.max_t);
+                  } else {
+                    h1 = slab_fast(f3{na.x, na.y, na.z}, f3{na.w, nb.x, nb.y}, c.ray.o, c.inv, c.ray.min_t, c.ray.max_t);
+                    h2 = slab_fast(f3{nb.z, nb.w, nc.x}, f3{nc.y, nc.z, nc.w}, c.ray.o, c.inv, c.ray.min_t, c.ray.max_t);
+                  }
+                  const bool in1 = !is_inf(h1), in2 = !is_inf(h2);
+                  const uint32_t c1 = refs.x, c2 = refs.y;
+                  // branch-free step: the entry a pop would return was read before the box test (its
+                  // latency hides behind the test); the far child is written above the top of the
+                  // stack whether it is kept or not (the slot is free), and sp moves by select
+                  const bool both = in1 && in2, any = in1 || in2;
+                  const bool first_is_near = c.any ? false : (h2 > h1);
+                  const uint32_t near_c = first_is_near ? c1 : c2;
+                  const uint32_t far_c = first_is_near ? c2 : c1;
+                  stack0[k * kstride + c.sp * 64] = far_c;
+                  const uint32_t one_c = in1 ? c1 : c2;
+                  c.cur = both ? near_c : (any ? one_c : (c.sp != 0 ? popped : REF_DONE));
+                  c.sp = both ? c.sp + 1 : (any ? c.sp : sp_below);
                 }
-                const bool in1 = !is_inf(h1), in2 = !is_inf(h2);
-                const uint32_t c1 = refs[k].x, c2 = refs[k].y;
-                // branch-free step: the entry a pop would return was read before the box test (its
-                // latency hides behind the test); the far child is written above the top of the
-                // stack whether it is kept or not (the slot is free), and sp moves by select
-                const bool both = in1 && in2, any = in1 || in2;
-                const bool first_is_near = c.any ? false : (h2 > h1);
-                const uint32_t near_c = first_is_near ? c1 : c2;
-                const uint32_t far_c = first_is_near ? c2 : c1;
-                stack0[k * kstride + c.sp * 64] = far_c;
-                const uint32_t one_c = in1 ? c1 : c2;
-                const uint32_t next_cur = both ? near_c : (any ? one_c : (c.sp != 0 ? popped[k] : REF_DONE));
-                const uint32_t next_sp = both ? c.sp + 1 : (any ? c.sp : sp_below[k]);
-                c.cur = act[k] ? next_cur : c.cur;
-                c.sp = act[k] ? next_sp : c.sp;
               }
               // deep trees: when only a few rays still descend, the ones that wait at a leaf go first
               // (the box loop of the config-5 stand-in ran with 27 % of its lanes busy)
