@@ -12,9 +12,9 @@ frames = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 s = scenes.json_scene("disney_spheres.json")
 p = s.default_params(samples=spp)
-os.environ["VIMG_HIP_POOL"] = "0"
+os.environ["VIMG_HIP_SCHED"] = "lane"
 ref, st0 = hip.DeviceScene(s).render(p)
-del os.environ["VIMG_HIP_POOL"]
+del os.environ["VIMG_HIP_SCHED"]
 d = hip.DeviceScene(s)
 print("reference:", st0.rays, "rays; pooled kernel:", d.kernel, flush=True)
 bad = 0

@@ -7,7 +7,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["VIMG_HIP_DIAG"] = "1"
 os.environ["VIMG_HIP_LIB"] = os.path.join(ROOT, "v-img_amd", "lib", "prof", "libvimg_hip.so")
-os.environ.setdefault("VIMG_HIP_POOL", "1")
+os.environ.setdefault("VIMG_HIP_SCHED", "pool")   # the stage timers live in render_pool_kernel
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import scenes
 from vimg_amd import hip

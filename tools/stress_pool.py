@@ -16,9 +16,9 @@ knobs = {"VIMG_HIP_POOL_SLOTS": ["8", "17", "64"], "VIMG_HIP_POOL_SEGMENTS": ["1
 bad = n = 0
 for name, s, kw in cases:
     p = s.default_params(**kw)
-    os.environ["VIMG_HIP_POOL"] = "0"
+    os.environ["VIMG_HIP_SCHED"] = "lane"
     ref, st0 = hip.DeviceScene(s).render_to_host(p)
-    os.environ["VIMG_HIP_POOL"] = "1"
+    os.environ["VIMG_HIP_SCHED"] = os.environ.get("STRESS_SCHED", "pool4")
     for combo in itertools.product(*knobs.values()):
         for k, v in zip(knobs, combo):
             os.environ[k] = v
