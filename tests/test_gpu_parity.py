@@ -850,6 +850,76 @@ def test_gpu_builders_give_a_valid_tree_and_the_same_picture(name, builder):
     assert same > 0.97 and abs(gpu.mean() - sah_img.mean()) <= 0.03 * abs(sah_img.mean()) + 1e-6
 
 
+@pytest.mark.parametrize("leaf_cap", [10 ** 9, 300])
+def test_leaves_of_more_than_127_primitives(leaf_cap):
+    """A caller's builder may hand over leaves larger than the 7-bit count of the packed child
+    reference (this repository's builders stop at 8).  The upload chains such a leaf (127 primitives
+    per link, the leaf's own box on both sides) so that its primitives are still tested in
+    obj_indices order: the image equals the oracle's on the SAME tree - a single leaf with all 420
+    primitives of the scene, then a median split into two leaves of ~250 - on the lane-bound and the
+    pooled kernel; only the event counts gain the chains' node visits."""
+    import ctypes as C
+    from vimg_amd import abi
+    BUILDER = C.CFUNCTYPE(C.c_int, C.c_uint32, abi.Pf32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                          C.c_void_p, abi.Pf32, C.POINTER(C.c_uint32))
+
+    def big_leaves(n, bounds6, num_nodes, max_depth, nodes_p, bb_p, obj_p):
+        b = np.ctypeslib.as_array(bounds6, (n, 6)).copy()
+        nodes = np.ctypeslib.as_array(C.cast(nodes_p, C.POINTER(C.c_uint32)), (2 * n - 1, 2))
+        bb = np.ctypeslib.as_array(bb_p, (2 * (2 * n - 1) + 3, 3))
+        obj = np.ctypeslib.as_array(obj_p, (n,))
+        centre = (b[:, :3] + b[:, 3:]) * 0.5
+        state = {"next": 1, "pos": 0, "depth": 0}
+
+        def box(ids):
+            return b[ids, :3].min(0), b[ids, 3:].max(0)
+
+        def build(node, ids, d):
+            state["depth"] = max(state["depth"], d)
+            if len(ids) <= leaf_cap:
+                nodes[node] = (state["pos"], len(ids))
+                obj[state["pos"]:state["pos"] + len(ids)] = ids
+                state["pos"] += len(ids)
+                return
+            lo, hi = box(ids)
+            axis = int(np.argmax(hi - lo))
+            order = ids[np.argsort(centre[ids, axis], kind="stable")]
+            halves = (order[:len(ids) // 2], order[len(ids) // 2:])
+            first = state["next"]
+            state["next"] += 2
+            nodes[node] = (first, 0)
+            for k in (0, 1):
+                c_lo, c_hi = box(halves[k])
+                bb[2 * first + 2 + k], bb[2 * first + 4 + k] = c_lo, c_hi
+            build(first, halves[0], d + 1)
+            build(first + 1, halves[1], d + 1)
+
+        ids = np.arange(n)
+        bb[0], bb[2] = box(ids)
+        build(0, ids, 1)
+        num_nodes[0], max_depth[0] = state["next"], state["depth"]
+        return 0
+
+    cb = BUILDER(big_leaves)
+    s = scenes.big_mesh_scene(res=(64, 48), n=14)       # 2 * 14 * 14 = 392 triangles + walls and a light
+    n = s.view.contents.num_prims
+    assert n > 2 * 127
+    p = s.default_params(samples=4)
+    sah, _ = _dev(s).render_to_host(p)
+    s.build_bvh_with(C.cast(cb, C.c_void_p))
+    bvh = s.view.contents.bvh
+    biggest = max(bvh.nodes[i].obj_count for i in range(bvh.num_nodes))
+    assert biggest > 127 and (biggest == n) == (leaf_cap > n)
+    cpu, cst, _ = O.render(s, p)
+    for sched in ("lane", "pool4"):
+        gpu, gst = _dev_opts(s, scheduler=sched, **({"pool_slots": 40} if sched == "pool4" else {})).render_to_host(p)
+        _compare_images(gpu, cpu, f"leaves of up to {biggest} primitives ({sched})", min_exact=0.995)
+        assert gst.paths == cst.paths and gst.rays == cst.rays and gst.prim_tests <= cst.prim_tests
+        assert gst.internal_visits > cst.internal_visits          # the chains' links
+    same = (gpu.view(np.uint32) == sah.view(np.uint32)).all(axis=-1).mean()
+    assert same > 0.97
+
+
 def test_bench_self_launches_two_ranks():
     """`python bench.py --gpus 2` with no rendezvous in the environment must start the ranks itself
     (fresh child processes; the driver invokes it exactly like this) and relay one JSON line.

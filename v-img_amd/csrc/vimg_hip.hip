@@ -747,9 +747,44 @@ int vimg_hip_scene_upload_opts(const VimgScene* sc, const VimgHipOptions* opts, 
   // that the lowest indices are the top of the tree — the part staged into LDS.  Traversal order
   // depends on the tree, not on the numbering, so results are unchanged.
   const VimgBVH& b = sc->bvh;
-  auto pack_leaf = [&](const VimgBVHNode& n, uint32_t& out) {
-    if (n.obj_count > 127 || n.first_index >= (1u << 25)) return false;
-    out = (n.obj_count << 25) | n.first_index;
+  // A child reference packs "count << 25 | first leaf slot": 7 bits of count.  A leaf of more than
+  // 127 primitives (no builder of this repository makes one - theirs stop at 8 - but a caller's
+  // builder may) becomes a CHAIN of extra records: the first 127 primitives as the RIGHT child, the
+  // rest as the left one, both with the leaf's own box.  With equal boxes the walk takes the right
+  // child first (closest hit: `h2 > h1` is false; any hit: second sibling first), so the
+  // primitives are still tested in obj_indices order, and a chunk the shortened ray no longer
+  // reaches holds no hit the reference could have accepted (its entry distance exceeds maxT).
+  // Images are identical; the event counts gain the chain's node visits.
+  std::vector<DNode> extra;          // chain records, appended behind the tree's own
+  uint32_t extra_depth = 0;
+  size_t n_internal = 0;             // set below, before the first chain is made
+  auto leaf_ref = [&](const VimgBVHNode& n, const float* bmin, const float* bmax, uint32_t& out) {
+    if (uint64_t(n.first_index) + n.obj_count > (1u << 25)) return false;
+    uint32_t first = n.first_index, count = n.obj_count, links = 0;
+    if (count <= 127u) {
+      out = (count << 25) | first;
+      return true;
+    }
+    // build the chain back to front: the last link's left child is the (<= 127) remainder
+    std::vector<std::pair<uint32_t, uint32_t>> chunks;   // (first, count) in test order
+    while (count > 127u) {
+      chunks.push_back({first, 127u});
+      first += 127u, count -= 127u;
+    }
+    uint32_t rest = (count << 25) | first;
+    for (size_t i = chunks.size(); i-- > 0;) {
+      DNode dn{};
+      dn.a = v4f{bmin[0], bmin[1], bmin[2], bmax[0]};
+      dn.b = v4f{bmax[1], bmax[2], bmin[0], bmin[1]};
+      dn.c = v4f{bmin[2], bmax[0], bmax[1], bmax[2]};
+      dn.left_ref = rest;
+      dn.right_ref = (chunks[i].second << 25) | chunks[i].first;
+      extra.push_back(dn);
+      rest = static_cast<uint32_t>(n_internal + extra.size() - 1);
+      ++links;
+    }
+    extra_depth = std::max(extra_depth, links);
+    out = rest;
     return true;
   };
   std::vector<uint32_t> order;   // internal nodes: new index -> old index
@@ -763,24 +798,24 @@ int vimg_hip_scene_upload_opts(const VimgScene* sc, const VimgHipOptions* opts, 
         order.push_back(c);
       }
   }
-  if (order.size() >= (1u << 25)) return bail(fail(VIMG_E_UNSUPPORTED, "BVH has more than 2^25 internal nodes"));
+  n_internal = order.size();
   std::vector<DNode> nodes(order.size());
   for (size_t i = 0; i < order.size(); ++i) {
     const VimgBVHNode& n = b.nodes[order[i]];
     DNode dn{};
     uint32_t refs[2];
+    const float* bb = b.bb_mins_maxes + (size_t(n.first_index) * 2 + 2) * 3;
+    const float* lmin = bb, *rmin = bb + 3, *lmax = bb + 6, *rmax = bb + 9;
     for (int k = 0; k < 2; ++k) {
       const uint32_t c = n.first_index + k;
       if (b.nodes[c].obj_count == 0) {
         refs[k] = new_of[c];
-      } else if (!pack_leaf(b.nodes[c], refs[k])) {
-        return bail(fail(VIMG_E_UNSUPPORTED, "BVH leaf with more than 127 primitives or more than 2^25 primitives"));
+      } else if (!leaf_ref(b.nodes[c], k == 0 ? lmin : rmin, k == 0 ? lmax : rmax, refs[k])) {
+        return bail(fail(VIMG_E_UNSUPPORTED, "BVH with more than 2^25 primitives"));
       }
     }
     dn.left_ref = refs[0];
     dn.right_ref = refs[1];
-    const float* bb = b.bb_mins_maxes + (size_t(n.first_index) * 2 + 2) * 3;
-    const float* lmin = bb, *rmin = bb + 3, *lmax = bb + 6, *rmax = bb + 9;
     dn.a = v4f{lmin[0], lmin[1], lmin[2], lmax[0]};
     dn.b = v4f{lmax[1], lmax[2], rmin[0], rmin[1]};
     dn.c = v4f{rmin[2], rmax[0], rmax[1], rmax[2]};
@@ -788,15 +823,18 @@ int vimg_hip_scene_upload_opts(const VimgScene* sc, const VimgHipOptions* opts, 
   }
   if (b.nodes[0].obj_count == 0) {
     d.root_ref = 0;
-  } else if (!pack_leaf(b.nodes[0], d.root_ref)) {
-    return bail(fail(VIMG_E_UNSUPPORTED, "single-leaf BVH with more than 127 primitives"));
+  } else if (!leaf_ref(b.nodes[0], b.bb_mins_maxes + 0, b.bb_mins_maxes + 6, d.root_ref)) {
+    return bail(fail(VIMG_E_UNSUPPORTED, "BVH with more than 2^25 primitives"));
   }
+  nodes.insert(nodes.end(), extra.begin(), extra.end());
+  if (nodes.size() >= (1u << 25)) return bail(fail(VIMG_E_UNSUPPORTED, "BVH has more than 2^25 internal nodes"));
   for (int a = 0; a < 3; ++a) {
     d.root_min[a] = b.bb_mins_maxes[0 * 3 + a];
     d.root_max[a] = b.bb_mins_maxes[2 * 3 + a];
   }
   d.num_nodes = static_cast<uint32_t>(nodes.size());
-  d.max_depth = b.max_depth;
+  if (b.max_depth + extra_depth + 2 > 96) return bail(fail(VIMG_E_INVALID, "BVH (with its leaf chains) deeper than the 94-level stack bound"));
+  d.max_depth = b.max_depth + extra_depth;   // a chain link pushes one entry like any internal node
 
   // ---- per-triangle shading records and leaf slots
   std::vector<DTriShade> shade(sc->num_tris);
