@@ -398,6 +398,36 @@ def test_config_standins_at_full_size_properties(name):
         assert np.allclose(img[h - 1 - y, x], ref, rtol=2e-5, atol=1e-6)
 
 
+def test_default_stream_launches_are_ordered_with_torch():
+    """`stream=None` means torch's current stream, not the library's private non-blocking one: a
+    shard rendered into a slab the wrapper allocates (torch.zeros on the current stream, then the
+    kernel) must come out complete every time - with an unordered launch the zero fill can land
+    after the kernel's writes - and a torch consumer enqueued right behind the render sees the
+    finished pixels."""
+    import torch
+    from vimg_amd import dist as vdist
+    s = scenes.json_scene("disney_spheres.json", res=(264, 120))
+    d = _dev(s)
+    w, h = s.resolution
+    full, _ = d.render(s.default_params(samples=4))
+    p = s.default_params(samples=4, tile_rank=1, tile_world=3)
+    stride = vdist.shard_stride_pixels(w, h, 3)
+    mask = np.zeros((3, stride, 3), dtype=np.float32)
+    mask[1, :d.shard_pixels(p)] = 1
+    own = vdist.assemble_numpy(mask, w, h, 3)[..., 0] > 0
+    want = full.cpu().numpy()[own]
+    for _ in range(20):
+        junk = torch.full((stride, 3), 7.0, device="cuda")      # keeps the current stream busy before the launch
+        slab, _ = d.render(p)                                   # out=None: allocated and zero-filled by the wrapper
+        total = slab.sum()                                      # consumer on the current stream, no host sync in between
+        gathered = np.zeros((3, stride, 3), dtype=np.float32)
+        gathered[1, :slab.shape[0]] = slab.cpu().numpy()
+        got = vdist.assemble_numpy(gathered, w, h, 3)[own]
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert abs(float(total) - float(want.sum())) <= 1e-3 * abs(float(want.sum()))
+        del junk
+
+
 def test_full_size_properties_disney_spheres():
     """BASELINE config 2 at full resolution, few samples: size-independent properties."""
     s = scenes.json_scene("disney_spheres.json")
