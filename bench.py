@@ -15,8 +15,9 @@ interleave, include/integrators.h:57-65,101), and the per-rank framebuffer slabs
 per step with RCCL (one all_gather of equal padded slabs) and de-interleaved — no collective on
 the data path.  Scaling is STRONG: the frame stays 1800x800 at 512 spp, `value` is the rays of
 that frame over the slowest rank's time; rank 0 also times the whole frame alone once (untimed
-extra) so that the line carries t1_ms and efficiency = T1 / (N * T_N).  `--weak` grows the image
-with sqrt(N) per axis instead (every GPU keeps 1800x800 pixels).
+extra) so that the line carries t1_ms and efficiency = T1 / (N * T_N), and the weak-scaling figure
+rides along under "weak" (the frame grown with sqrt(N) per axis: every GPU keeps 1800x800 pixels).
+`--weak` makes that frame the headline instead.
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement).
 """
@@ -182,6 +183,7 @@ def main():
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--res", type=int, nargs=2, default=None, help="rehearsal: another frame size")
+    ap.add_argument("--no-weak-leg", action="store_true", help="N>1: skip the weak-scaling figure that rides along")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -206,78 +208,80 @@ def main():
 
     n = world
     base = tuple(args.res) if args.res else (1800, 800)
-    if n == 1 or not args.weak:
-        res = base
-    else:
-        res = (8 * round(base[0] * math.sqrt(n) / 8), 8 * round(base[1] * math.sqrt(n) / 8))
-    scene = load_scene(res)
-    dev = hip.DeviceScene(scene)
-    params = scene.default_params(samples=args.spp, tile_rank=rank, tile_world=n)
-    kernel_name = dev.kernel_for(params)
-    W, H = res
+    grown = (8 * round(base[0] * math.sqrt(n) / 8), 8 * round(base[1] * math.sqrt(n) / 8))
+    res = base if (n == 1 or not args.weak) else grown
     # a dedicated (non-default) stream: the kernels are launched on it and the HIP events that
     # time them are recorded on it
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
-
-    if n == 1:
-        frame = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
-        slab = frame
-    else:
-        stride = vdist.shard_stride_pixels(W, H, n)
-        slab = torch.zeros((stride, 3), dtype=torch.float32, device="cuda")
-        gathered = torch.empty((n * stride, 3), dtype=torch.float32, device="cuda")
-        frame = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
-
-    def step(ev=None):
-        if ev is not None:
-            ev[0].record(stream)
-        dev.render_async(params, slab, stream=stream)
-        if ev is not None:
-            ev[1].record(stream)
-        if n > 1:
-            if args.backend == "nccl":
-                dist.all_gather_into_tensor(gathered, slab)     # RCCL over xGMI, once per frame
-            else:
-                host = torch.empty(gathered.shape, dtype=torch.float32)
-                dist.all_gather_into_tensor(host, slab.cpu())
-                gathered.copy_(host)
-            dev.assemble_shards(gathered, n, stride, out=frame, stream=stream)
-
-    # event counts of one step (deterministic: same seeds every step); not timed
-    _, st = dev.render(params, out=slab, stats=True, stream=stream)
-    local_pixels = st.paths // args.spp
     red_dev = "cuda" if args.backend == "nccl" else "cpu"
-    counts = torch.tensor([st.rays, st.paths, algorithmic_bytes(st, local_pixels)],
-                          dtype=torch.float64, device=red_dev)
-    if n > 1:
-        dist.all_reduce(counts)
-    total_rays, total_paths = float(counts[0]), float(counts[1])
-    local_bytes = algorithmic_bytes(st, local_pixels)
 
-    for _ in range(args.warmup):
-        step()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for _ in range(args.steps)]
-    if n > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(events[k])
-    torch.cuda.synchronize()
-    if n > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    if n > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t[0])
-    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / args.steps
-    kms = torch.tensor([kernel_ms], dtype=torch.float64, device=red_dev)
-    if n > 1:
-        dist.all_reduce(kms, op=dist.ReduceOp.MAX)
-    kernel_ms_max = float(kms[0])
+    def measure(res, steps, warmup):
+        """W warm-up steps, then exactly `steps` steps of one frame of `res` between barriers;
+        returns the slowest rank's wall time and what was rendered."""
+        scene = load_scene(res)
+        dev = hip.DeviceScene(scene)
+        params = scene.default_params(samples=args.spp, tile_rank=rank, tile_world=n)
+        W, H = res
+        if n == 1:
+            frame = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+            slab, gathered, stride = frame, None, 0
+        else:
+            stride = vdist.shard_stride_pixels(W, H, n)
+            slab = torch.zeros((stride, 3), dtype=torch.float32, device="cuda")
+            gathered = torch.empty((n * stride, 3), dtype=torch.float32, device="cuda")
+            frame = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+
+        def step(ev=None):
+            if ev is not None:
+                ev[0].record(stream)
+            dev.render_async(params, slab, stream=stream)
+            if ev is not None:
+                ev[1].record(stream)
+            if n > 1:
+                if args.backend == "nccl":
+                    dist.all_gather_into_tensor(gathered, slab)     # RCCL over xGMI, once per frame
+                else:
+                    host = torch.empty(gathered.shape, dtype=torch.float32)
+                    dist.all_gather_into_tensor(host, slab.cpu())
+                    gathered.copy_(host)
+                dev.assemble_shards(gathered, n, stride, out=frame, stream=stream)
+
+        # event counts of one step (deterministic: same seeds every step); not timed
+        _, st = dev.render(params, out=slab, stats=True, stream=stream)
+        local_pixels = st.paths // args.spp
+        local_bytes = algorithmic_bytes(st, local_pixels)
+        counts = torch.tensor([st.rays, st.paths, local_bytes], dtype=torch.float64, device=red_dev)
+        if n > 1:
+            dist.all_reduce(counts)
+        for _ in range(warmup):
+            step()
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                  for _ in range(steps)]
+        if n > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(events[k])
+        torch.cuda.synchronize()
+        if n > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = sum(a.elapsed_time(b) for a, b in events) / steps
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=red_dev)
+        if n > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return {"scene": scene, "dev": dev, "params": params, "frame": frame, "res": res,
+                "elapsed": float(t[0]), "kernel_ms": kernel_ms, "kernel_ms_max": float(t[1]),
+                "rays": float(counts[0]), "paths": float(counts[1]), "local_bytes": local_bytes,
+                "kernel": dev.kernel_for(params)}
+
+    m = measure(res, args.steps, args.warmup)
+    scene, dev, frame = m["scene"], m["dev"], m["frame"]
+    W, H = res
+    elapsed, kernel_ms, kernel_ms_max = m["elapsed"], m["kernel_ms"], m["kernel_ms_max"]
+    total_rays, total_paths, local_bytes, kernel_name = m["rays"], m["paths"], m["local_bytes"], m["kernel"]
 
     # untimed extra on rank 0 (strong scaling): the whole frame alone, for T1 and --verify
     t1_ms = None
@@ -296,6 +300,17 @@ def main():
             print("verify: assembled frame is bit-identical to the single-GPU frame", file=sys.stderr)
     if n > 1:
         dist.barrier()
+    # riding along for N > 1 (strong scaling is the headline): the same measurement on the frame grown
+    # with sqrt(N) per axis, where every GPU keeps 1800x800 pixels of work
+    weak = None
+    if n > 1 and not args.weak and not args.no_weak_leg:
+        try:
+            mw = measure(grown, args.steps, 1)
+            weak = {"resolution": list(grown), "ms_per_step": round(mw["elapsed"] / args.steps * 1e3, 3),
+                    "value": round(mw["rays"] * args.steps / mw["elapsed"] / 1e6, 2), "unit": "Mrays/s",
+                    "kernel": mw["kernel"], "note": "weak scaling: 1800x800 pixels per GPU"}
+        except Exception as e:   # the headline must not die with the extra
+            weak = {"error": repr(e)[:200]}
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_rays * args.steps / elapsed / 1e6
@@ -326,6 +341,8 @@ def main():
             "kernel_ms": round(kernel_ms, 3),
             "kernel_ms_slowest_rank": round(kernel_ms_max, 3),
         }
+        if weak is not None:
+            out["weak"] = weak
         if strong and t1_ms is not None:
             out["t1_ms"] = round(t1_ms, 3)
             out["efficiency"] = round(t1_ms / (n * ms_per_step), 4)

@@ -969,5 +969,6 @@ def test_bench_self_launches_two_ranks():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["weak"]["value"] > 0 and out["weak"]["resolution"] == [648, 280]      # the sqrt(2)-grown frame rides along
     assert "verify: assembled frame is bit-identical" in r.stderr
     assert 0 < out["efficiency"] <= 1.5
