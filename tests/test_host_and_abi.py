@@ -40,10 +40,10 @@ def test_host_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_c_headers():
     # sizes the C compiler gives the boundary structs (checked against a tiny C probe)
     import subprocess, tempfile
-    src = '#include <stdio.h>\n#include "vimg_scene.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",' \
+    src = '#include <stdio.h>\n#include "vimg_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",' \
           'sizeof(VimgCamera),sizeof(VimgMesh),sizeof(VimgSphere),sizeof(VimgMaterial),sizeof(VimgTexture),' \
           'sizeof(VimgTextureRG),sizeof(VimgBackground),sizeof(VimgBVH),sizeof(VimgScene),' \
-          'sizeof(VimgRenderParams),sizeof(VimgRenderStats));return 0;}\n'
+          'sizeof(VimgRenderParams),sizeof(VimgRenderStats),sizeof(VimgHipOptions));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "p.c"), "w").write(src)
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "p.c"), "-o",
@@ -52,8 +52,13 @@ def test_struct_layouts_match_the_c_headers():
                                               text=True, check=True).stdout.split()]
     want = [C.sizeof(t) for t in (abi.Camera, abi.Mesh, abi.Sphere, abi.Material, abi.Texture,
                                   abi.TextureRG, abi.Background, abi.BVH, abi.Scene,
-                                  abi.RenderParams, abi.RenderStats)]
+                                  abi.RenderParams, abi.RenderStats, abi.HipOptions)]
     assert got == want
+    # vimg_hip_options_default fills every field with VIMG_OPT_AUTO, which is what the ctypes mirror starts from
+    lib = abi.hip_lib()
+    a, b = abi.HipOptions(scheduler=2), abi.HipOptions()
+    lib.vimg_hip_options_default(C.byref(a))
+    assert bytes(a) == bytes(b) and a.struct_size == C.sizeof(abi.HipOptions) and a.scheduler == abi.OPT_AUTO
 
 
 def test_hip_path_fails_loudly_without_a_gpu():
