@@ -43,6 +43,13 @@ v-img_amd/lib/prof/libvimg_hip.so: $(HIPSRC) $(HIPHDR) Makefile
 	@mkdir -p v-img_amd/lib/prof
 	$(HIPCC) $(HIPFLAGS) -DVIMG_PROFILE=1 $(HIPSRC) -o $@
 
+# measurement build: cycle and trip counters inside the walk stage of render_pool4_kernel
+# (VIMG_HIP_DIAG=1 prints them after a stats launch); selected with VIMG_HIP_LIB by tools/walk_diag.sh
+diag: v-img_amd/lib/diag/libvimg_hip.so
+v-img_amd/lib/diag/libvimg_hip.so: $(HIPSRC) $(HIPHDR) Makefile
+	@mkdir -p v-img_amd/lib/diag
+	$(HIPCC) $(HIPFLAGS) -DVIMG_WALK_DIAG=1 $(HIPSRC) -o $@
+
 # C++ host program (the counterpart of the reference's main): links both libraries by rpath
 v-img_amd/bin/vimg-amd: v-img_amd/cli/main.cpp $(LIBDIR)/libvimg_host.so $(LIBDIR)/libvimg_hip.so Makefile
 	@mkdir -p v-img_amd/bin
@@ -68,4 +75,4 @@ oracle/liboracle_avx2.so: $(ORASRC) $(ORAHDR) Makefile
 clean:
 	rm -f $(LIBDIR)/*.so oracle/*.so
 
-.PHONY: all host hip oracle oracle-avx2 cli clean prof
+.PHONY: all host hip oracle oracle-avx2 cli clean prof diag

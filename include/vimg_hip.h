@@ -68,6 +68,7 @@ typedef struct VimgHipOptions {
   int32_t stage_wchunk;       /* STAGE: slot ids a walking wave stages in LDS, 128..256.  AUTO 128 */
   int32_t stage_walk_quota;   /* STAGE: rays a wave walks before it looks at the queues again.  AUTO 2048 */
   int32_t pool4_rays;         /* reserved (two rays per lane in the walk measured slower; 1 is what runs) */
+  int32_t lds_stack;          /* POOL4, trees beyond LDS: entries of a lane's traversal stack kept in LDS, the rest in global memory.  AUTO 32 */
 } VimgHipOptions;
 /* Fills every field with VIMG_OPT_AUTO (and struct_size). */
 void vimg_hip_options_default(VimgHipOptions* opts);

@@ -102,6 +102,10 @@ SCHEDULES = {
     "pool4": dict(scheduler="pool4"),
     "pool4/5": dict(scheduler="pool4", pool_segments=5),
     "pool4/4": dict(scheduler="pool4", waves_per_simd=4, pool_segments=3),
+    # trees beyond LDS keep only the first entries of a lane's traversal stack in LDS and the rest
+    # in global memory: here one entry / three, so that nearly every push and pop takes that path
+    "pool4/stack1": dict(scheduler="pool4", lds_stack=1),
+    "pool4/stack3": dict(scheduler="pool4", lds_stack=3, pool_segments=2),
     # the staged kernel: as many slots as pixels (policy), then far fewer slots than pixels so that
     # pixels queue in the ready FIFO, one-sample and whole-pixel segments, the smallest walk chunk
     "stage": dict(scheduler="stage"),
@@ -167,7 +171,7 @@ def test_pooled_and_staged_schedulers_on_every_feature(case):
     s, kw = mk()
     p = s.default_params(**kw)
     lane, st_lane = _dev_opts(s, scheduler="lane").render_to_host(p)
-    for name in ("pool", "pool/5", "pool4", "pool4/5", "pool4/4", "stage", "stage/few"):
+    for name in ("pool", "pool/5", "pool4", "pool4/5", "pool4/4", "pool4/stack1", "pool4/stack3", "stage", "stage/few"):
         d = _dev_opts(s, **SCHEDULES[name])
         img, st = d.render_to_host(p)
         assert np.array_equal(img.view(np.uint32), lane.view(np.uint32)), (case, name, d.kernel)

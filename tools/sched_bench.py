@@ -17,6 +17,12 @@ which = pos[1] if len(pos) > 1 else "disney"
 tw, tr = int(kv.pop("tile_world", 1)), int(kv.pop("tile_rank", 0))
 res = tuple(int(v) for v in kv.pop("res").split("x")) if "res" in kv else None
 steps = int(kv.pop("steps", 2))
+scene_kw = {}          # stand-in parameters: n_lat= / env=WxH (config4), n= / tex= (config5)
+for k in ("n_lat", "n", "tex"):
+    if k in kv:
+        scene_kw[k] = int(kv.pop(k))
+if "env" in kv:
+    scene_kw["env"] = tuple(int(v) for v in kv.pop("env").split("x"))
 opts = {k: int(v) for k, v in kv.items()}
 if sched != "auto":
     opts["scheduler"] = sched
@@ -24,7 +30,8 @@ hip.init(0)
 if which == "disney":
     s = scenes.json_scene("disney_spheres.json", res=res)
 else:
-    s = {"config3": scenes.config3_scene, "config4": scenes.config4_scene, "config5": lambda: scenes.config5_scene(n=700)}[which]()
+    s = {"config3": scenes.config3_scene, "config4": scenes.config4_scene,
+         "config5": lambda **kw: scenes.config5_scene(**{"n": 700, **kw})}[which](**scene_kw)
 d = hip.DeviceScene(s, **opts)
 p = s.default_params(samples=spp, tile_rank=tr, tile_world=tw)
 w, h = s.resolution
@@ -34,5 +41,5 @@ _, st = d.render(p, out=out)
 ms = d.time_renders(p, out, steps)
 sec = float(ms.min()) * 1e-3
 print(json.dumps({"scheduler": sched, "kernel": d.kernel_for(p), "scene": which, "res": [w, h], "spp": spp, "tile_world": tw,
-                  "opts": opts, "ms": [round(float(m), 2) for m in ms], "mrays_per_s": round(st.rays / sec / 1e6, 1),
+                  "opts": {**opts, **scene_kw}, "ms": [round(float(m), 2) for m in ms], "mrays_per_s": round(st.rays / sec / 1e6, 1),
                   "rays": st.rays}), flush=True)

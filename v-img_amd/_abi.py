@@ -135,7 +135,7 @@ class HipOptions(C.Structure):
                 ("pool_refill", i32), ("pool_vbatch", i32), ("pool_classes", i32),
                 ("pool_starve", i32), ("pool_boxmin", i32), ("lds_leaf", i32),
                 ("stage_slots", i32), ("stage_seg_len", i32), ("stage_wchunk", i32),
-                ("stage_walk_quota", i32), ("pool4_rays", i32)]
+                ("stage_walk_quota", i32), ("pool4_rays", i32), ("lds_stack", i32)]
 
     def __init__(self, **kw):
         super().__init__()

@@ -113,6 +113,9 @@ struct RenderArgs {
   uint32_t full_stats;
   uint32_t stack_entries;           // per-lane LDS stack depth (max_depth + 2)
   uint32_t lds_nodes;               // number of top-of-tree nodes staged into LDS
+  uint32_t stack_lds;               // pool4, deep trees: stack entries kept in LDS (== stack_entries: all of them);
+                                    // the LDS stack then has stack_lds + 1 rows (the last one takes the writes above)
+  VIMG_GLOBAL uint32_t* stack_ovf;  // pool4: the entries beyond, [wave of the grid][entry - stack_lds][lane] (scene-owned scratch)
   VIMG_GLOBAL v4u* pool_cold;       // pooled kernel: cold slot records, [wave][slot][record] (scene-owned scratch)
   uint32_t lds_leaf;                // pooled kernel: number of leaf records copied to LDS (all or 0)
   VIMG_GLOBAL v4u* pool_state;      // pooled kernel: per work item {rng lo, rng hi, epoch + segments done, -}{acc.xyz, -}

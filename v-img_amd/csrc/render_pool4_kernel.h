@@ -50,6 +50,9 @@ struct Pool4Wave {
   uint32_t pad[2];
 };
 static_assert(sizeof(Pool4Wave) == 64, "Pool4Wave is one 64-byte record");
+// rows of a lane's LDS stack: all entries, or the first stack_lds and one more that takes the
+// writes of the entries kept in global memory
+__host__ __device__ constexpr uint32_t pool4_stack_rows_of(uint32_t entries, uint32_t in_lds) { return in_lds < entries ? in_lds + 1u : entries; }
 // diagnostics of full-stats launches (VIMG_HIP_DIAG prints them): cycles in vertex calls by class
 // (0 finisher, 1 Lambertian, 2 Principled, 3 other), in the walk stage (4) and idle (5); batches and
 // slots per class
@@ -499,12 +502,7 @@ __device__ __noinline__ void pool4_vertex(uint32_t k_lo, uint32_t k_hi, VIMG_LDS
       const uint32_t leader = __ffsll(static_cast<long long>(mask)) - 1;
       if (lane == leader) base = atomicAdd(work_counter, cntp);
       base = __shfl(base, leader);
-      if (base >= total_claims) {
-        pixels_left = false;
-#ifdef VIMG_PROFILE
-        prof_acc[PF_DRAIN] = __builtin_readcyclecounter();   // time stamp: turned into a span at exit
-#endif
-      }
+      if (base >= total_claims) pixels_left = false;
     }
     if (want) {
       claim = pixels_left ? base + lane_rank(mask, lane) : total_claims;
@@ -656,9 +654,9 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
   VIMG_LDS uint32_t* stack0;   // this lane's stack of its first ray: entry k at stack0[k * 64]; second ray: + stack_entries * 64
   {
     const uint32_t node_bytes = (lds_node_bytes(A.lds_nodes) + 255u) & ~255u;
-    const uint32_t stack_bytes = 4u * uint32_t(NC) * A.stack_entries * 64u * 4u;   // [wave][ray of the lane][entry][lane]
+    const uint32_t stack_bytes = 4u * uint32_t(NC) * pool4_stack_rows_of(A.stack_entries, A.stack_lds) * 64u * 4u;   // [wave][ray of the lane][entry][lane]
     stack0 = reinterpret_cast<VIMG_LDS uint32_t*>((VIMG_LDS unsigned char*)lds_raw + node_bytes) +
-             size_t(wave) * NC * A.stack_entries * 64u + lane;
+             size_t(wave) * NC * pool4_stack_rows_of(A.stack_entries, A.stack_lds) * 64u + lane;
     const uint32_t per_wave = pool4_wave_bytes(P) / 4u;   // in dwords
     VIMG_LDS uint32_t* base =
         reinterpret_cast<VIMG_LDS uint32_t*>((VIMG_LDS unsigned char*)lds_raw + node_bytes + stack_bytes);
@@ -727,7 +725,14 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
     C[k].rec.kind = 0;
     C[k].rec.e0 = C[k].rec.e1 = C[k].rec.e2 = C[k].rec.inv_det = 0.f;
   }
-  const uint32_t kstride = A.stack_entries * 64u;   // dwords between the stacks of a lane's two rays
+  const uint32_t kstride = pool4_stack_rows_of(A.stack_entries, A.stack_lds) * 64u;   // dwords between the stacks of a lane's two rays
+  // Deep trees: only the first S entries of a lane's stack live in LDS (a ray of a 25-level tree
+  // rarely holds more than a dozen), the rest in a per-wave region in global memory, so that the
+  // LDS they would take goes to path slots.  Row S of the LDS stack takes the branch-free step's
+  // writes and read-aheads of the entries above.
+  const uint32_t S = A.stack_lds;
+  const uint32_t ovf_stride = (A.stack_entries - S) * 64u;   // dwords between the overflow stacks of a lane's two rays
+  VIMG_GLOBAL uint32_t* ovf0 = A.stack_ovf + (size_t(blockIdx.x) * 4u + wave) * NC * ovf_stride + lane;
   auto count_ctx = [&](auto pred) {
     uint32_t n = 0;
 #pragma unroll
@@ -736,6 +741,15 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
   };
 
   unsigned long long t_mark = full_stats ? __builtin_readcyclecounter() : 0ull;
+#ifdef VIMG_WALK_DIAG   // measurement build only: where a walk round's cycles go (wave-uniform accumulators)
+  unsigned long long wd_fill = 0, wd_box = 0, wd_leaf = 0, wd_ret = 0, wd_t = 0;
+  unsigned long long wd_nbox = 0, wd_boxlanes = 0, wd_nleaf = 0, wd_leaflanes = 0, wd_primtrips = 0;
+#define WD_MARK() (wd_t = __builtin_readcyclecounter())
+#define WD_ADD(acc) do { const unsigned long long n_ = __builtin_readcyclecounter(); acc += n_ - wd_t; wd_t = n_; } while (0)
+#else
+#define WD_MARK() ((void)0)
+#define WD_ADD(acc) ((void)0)
+#endif
   for (;;) {
     const uint32_t n_walking = count_ctx([](const WalkCtx& c) { return c.slot != SLOT_IDLE; });
     const bool inflight = n_walking != 0u;
@@ -803,6 +817,7 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
       idle_polls = 0;
 
       for (;;) {
+        WD_MARK();
         // (1) idle rays of the lanes take queued slots
         {
           unsigned long long m[NC];
@@ -865,14 +880,86 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
           }
         }
 
+        WD_ADD(wd_fill);
         if (count_ctx([](const WalkCtx& c) { return c.slot != SLOT_IDLE; }) == 0u) break;
         // (3) walk until a quarter of the rays in flight have finished (or nothing is left to walk)
+        // One step of a ray that stands at an internal node, its record in hand.  Branch-free: the
+        // entry a pop would return is read before the box test (its latency hides behind the test);
+        // the far child is written above the top of the stack whether it is kept or not (the slot
+        // is free), and sp moves by select.
+        auto box_step = [&](WalkCtx& c, int k, v4f na, v4f nb, v4f nc, v2u refs, auto exact_possible) {
+          const uint32_t sp_below = c.sp != 0 ? c.sp - 1 : 0u;
+          uint32_t popped = stack0[k * kstride + (DEEP ? (sp_below < S ? sp_below : S) : sp_below) * 64];
+          cnt.internal += stat_inc;
+          float h1, h2;
+          if (decltype(exact_possible)::value && c.exact) {
+            h1 = slab(f3{na.x, na.y, na.z}, f3{na.w, nb.x, nb.y}, c.ray.o, c.inv, c.ray.min_t, c.ray.max_t);
+            h2 = slab(f3{nb.z, nb.w, nc.x}, f3{nc.y, nc.z, nc.w}, c.ray.o, c.inv, c.ray.min_t, c.ray.max_t);
+          } else {
+            h1 = slab_fast(f3{na.x, na.y, na.z}, f3{na.w, nb.x, nb.y}, c.ray.o, c.inv, c.ray.min_t, c.ray.max_t);
+            h2 = slab_fast(f3{nb.z, nb.w, nc.x}, f3{nc.y, nc.z, nc.w}, c.ray.o, c.inv, c.ray.min_t, c.ray.max_t);
+          }
+          const bool in1 = !is_inf(h1), in2 = !is_inf(h2);
+          const uint32_t c1 = refs.x, c2 = refs.y;
+          const bool both = in1 && in2, any = in1 || in2;
+          const bool first_is_near = c.any ? false : (h2 > h1);
+          const uint32_t near_c = first_is_near ? c1 : c2;
+          const uint32_t far_c = first_is_near ? c2 : c1;
+          stack0[k * kstride + (DEEP ? (c.sp < S ? c.sp : S) : c.sp) * 64] = far_c;
+          if constexpr (DEEP) {
+            if (both && c.sp >= S) ovf0[k * ovf_stride + (c.sp - S) * 64] = far_c;
+            if (!any && sp_below >= S) popped = ovf0[k * ovf_stride + (sp_below - S) * 64];   // (sp_below >= S > 0: sp != 0)
+          }
+          const uint32_t one_c = in1 ? c1 : c2;
+          c.cur = both ? near_c : (any ? one_c : (c.sp != 0 ? popped : REF_DONE));
+          c.sp = both ? c.sp + 1 : (any ? c.sp : sp_below);
+        };
+        // One primitive of a leaf against the ray, by select: a hit shortens the ray; an any-hit ray
+        // stops at its first hit (returned), a closest-hit ray keeps the record of the last success.
+        auto prim_step = [&](WalkCtx& c, v4f a, v4f b, v4f cc) -> bool {
+          const float c0 = cc.x;
+          const uint32_t lp_prim = __float_as_uint(cc.y), kind = __float_as_uint(cc.z),
+                         lp_cls = __float_as_uint(cc.w);   // DLeafPrim: c0 | prim | kind | cls
+          cnt.prim += stat_inc;
+          bool hit = false;
+          float t = 0.f, e0 = 0.f, e1 = 0.f, e2 = 0.f, idet = 0.f;
+          if (kind == 0) {
+            hit = tri_test_flat(f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c0}, c.ray, c.rc, t, e0, e1, e2, idet);
+          } else if (kind == 1) {
+            cnt.sphere += stat_inc;
+            hit = sphere_test(f3{a.x, a.y, a.z}, a.w, c.ray, c.dir_len2, t);
+          }
+          c.ray.max_t = hit ? t : c.ray.max_t;
+          c.found = c.found || hit;
+          const bool keep_rec = hit && !c.any;
+          c.rec.e0 = keep_rec ? e0 : c.rec.e0, c.rec.e1 = keep_rec ? e1 : c.rec.e1;
+          c.rec.e2 = keep_rec ? e2 : c.rec.e2, c.rec.inv_det = keep_rec ? idet : c.rec.inv_det;
+          c.rec.prim = keep_rec ? lp_prim : c.rec.prim;
+          c.rec.kind = keep_rec ? kind : c.rec.kind;
+          c.cls = keep_rec ? lp_cls : c.cls;
+          return hit && c.any;
+        };
+        // a leaf is done: the next node comes off the stack (or the ray is finished)
+        auto leaf_pop = [&](WalkCtx& c, int k, bool stop) {
+          const uint32_t sp_below = c.sp != 0 ? c.sp - 1 : 0u;
+          uint32_t popped = stack0[k * kstride + (DEEP ? (sp_below < S ? sp_below : S) : sp_below) * 64];
+          if constexpr (DEEP) {
+            if (!stop && sp_below >= S) popped = ovf0[k * ovf_stride + (sp_below - S) * 64];
+          }
+          c.cur = (stop || c.sp == 0) ? REF_DONE : popped;
+          c.sp = sp_below;
+        };
+        bool exact_any = false;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) exact_any = exact_any || (C[k].exact && C[k].slot != SLOT_IDLE);
+        const bool exact_round = __any(exact_any);   // (the rays of the lanes do not change inside (3))
+
         for (;;) {
-          // the box loop in two builds: rays with a zero direction component need the exact
-          // select form of the slab test (0 * inf); a round without such a ray runs the build
+          // "while-while": the box loop until every ray stands at a leaf (or is done), then the
+          // leaves.  The box loop comes in two builds: rays with a zero direction component need the
+          // exact select form of the slab test (0 * inf); a round without such a ray runs the build
           // that has only the min/max form.  One pass of the loop steps every ray of the lane that
-          // stands at an internal node; the step is branch-free (selects), so the passes of a
-          // lane's rays interleave in the instruction stream.
+          // stands at an internal node.
           auto box_loop = [&](auto exact_possible) {
             for (;;) {
               bool act[NC];
@@ -883,6 +970,9 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
                 any_act = any_act || act[k];
               }
               if (!__any(any_act)) break;
+#ifdef VIMG_WALK_DIAG
+              wd_nbox += 1, wd_boxlanes += __popcll(__ballot(act[0]));
+#endif
 #pragma unroll
               for (int k = 0; k < NC; ++k) {
                 WalkCtx& c = C[k];
@@ -899,30 +989,7 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
                     na = nd->a, nb = nd->b, nc = nd->c;
                     refs = v2u{nd->left_ref, nd->right_ref};
                   }
-                  const uint32_t sp_below = c.sp != 0 ? c.sp - 1 : 0u;
-                  const uint32_t popped = stack0[k * kstride + sp_below * 64];
-                  cnt.internal += stat_inc;
-                  float h1, h2;
-                  if (decltype(exact_possible)::value && c.exact) {
-                    h1 = slab(f3{na.x, na.y, na.z}, f3{na.w, nb.x, nb.y}, c.ray.o, c.inv, c.ray.min_t, c.ray.max_t);
-                    h2 = slab(f3{nb.z, nb.w, nc.x}, f3{nc.y, nc.z, nc.w}, c.ray.o, c.inv, c.ray.min_t, c.ray.max_t);
-                  } else {
-                    h1 = slab_fast(f3{na.x, na.y, na.z}, f3{na.w, nb.x, nb.y}, c.ray.o, c.inv, c.ray.min_t, c.ray.max_t);
-                    h2 = slab_fast(f3{nb.z, nb.w, nc.x}, f3{nc.y, nc.z, nc.w}, c.ray.o, c.inv, c.ray.min_t, c.ray.max_t);
-                  }
-                  const bool in1 = !is_inf(h1), in2 = !is_inf(h2);
-                  const uint32_t c1 = refs.x, c2 = refs.y;
-                  // branch-free step: the entry a pop would return was read before the box test (its
-                  // latency hides behind the test); the far child is written above the top of the
-                  // stack whether it is kept or not (the slot is free), and sp moves by select
-                  const bool both = in1 && in2, any = in1 || in2;
-                  const bool first_is_near = c.any ? false : (h2 > h1);
-                  const uint32_t near_c = first_is_near ? c1 : c2;
-                  const uint32_t far_c = first_is_near ? c2 : c1;
-                  stack0[k * kstride + c.sp * 64] = far_c;
-                  const uint32_t one_c = in1 ? c1 : c2;
-                  c.cur = both ? near_c : (any ? one_c : (c.sp != 0 ? popped : REF_DONE));
-                  c.sp = both ? c.sp + 1 : (any ? c.sp : sp_below);
+                  box_step(c, k, na, nb, nc, refs, exact_possible);
                 }
               }
               // deep trees: when only a few rays still descend, the ones that wait at a leaf go first
@@ -932,13 +999,21 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
               }
             }
           };
-          bool exact_any = false;
-#pragma unroll
-          for (int k = 0; k < NC; ++k) exact_any = exact_any || (C[k].exact && C[k].slot != SLOT_IDLE);
-          if (__any(exact_any))
+          WD_MARK();
+          if (exact_round)
             box_loop(std::true_type{});
           else
             box_loop(std::false_type{});
+          WD_ADD(wd_box);
+#ifdef VIMG_WALK_DIAG
+          {
+            const bool at_leaf = C[0].cur != REF_DONE && (!DEEP || ref_count(C[0].cur) != 0);
+            const uint32_t cnt_l = at_leaf ? ref_count(C[0].cur) : 0u;
+            uint32_t mx = cnt_l;
+            for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
+            wd_nleaf += 1, wd_leaflanes += __popcll(__ballot(at_leaf)), wd_primtrips += uni(mx);
+          }
+#endif
 
 #pragma unroll
           for (int k = 0; k < NC; ++k) {
@@ -957,42 +1032,18 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
                   a = lp->a, b = lp->b;
                   cc = reinterpret_cast<gptr<v4f>>(lp)[2];
                 }
-                const float c0 = cc.x;
-                const uint32_t lp_prim = __float_as_uint(cc.y), kind = __float_as_uint(cc.z),
-                               lp_cls = __float_as_uint(cc.w);   // DLeafPrim: c0 | prim | kind | cls
-                cnt.prim += stat_inc;
-                bool hit = false;
-                float t = 0.f, e0 = 0.f, e1 = 0.f, e2 = 0.f, idet = 0.f;
-                if (kind == 0) {
-                  hit = tri_test_flat(f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c0}, c.ray, c.rc, t, e0,
-                                      e1, e2, idet);
-                } else if (kind == 1) {
-                  cnt.sphere += stat_inc;
-                  hit = sphere_test(f3{a.x, a.y, a.z}, a.w, c.ray, c.dir_len2, t);
-                }
-                // by select: a hit shortens the ray; an any-hit ray stops at its first hit, a
-                // closest-hit ray keeps the record of the last success
-                c.ray.max_t = hit ? t : c.ray.max_t;
-                c.found = c.found || hit;
-                stop = hit && c.any;
-                const bool keep_rec = hit && !c.any;
-                c.rec.e0 = keep_rec ? e0 : c.rec.e0, c.rec.e1 = keep_rec ? e1 : c.rec.e1;
-                c.rec.e2 = keep_rec ? e2 : c.rec.e2, c.rec.inv_det = keep_rec ? idet : c.rec.inv_det;
-                c.rec.prim = keep_rec ? lp_prim : c.rec.prim;
-                c.rec.kind = keep_rec ? kind : c.rec.kind;
-                c.cls = keep_rec ? lp_cls : c.cls;
+                stop = prim_step(c, a, b, cc);
               }
-              const uint32_t sp_below = c.sp != 0 ? c.sp - 1 : 0u;
-              const uint32_t popped = stack0[k * kstride + sp_below * 64];
-              c.cur = (stop || c.sp == 0) ? REF_DONE : popped;
-              c.sp = sp_below;
+              leaf_pop(c, k, stop);
             }
           }
 
+          WD_ADD(wd_leaf);
           const uint32_t n_fin = count_ctx([](const WalkCtx& c) { return c.slot != SLOT_IDLE && c.cur == REF_DONE; });
           const uint32_t n_act = count_ctx([](const WalkCtx& c) { return c.slot != SLOT_IDLE && c.cur != REF_DONE; });
           if (n_act == 0 || n_fin >= A.pool_refill * NC) break;
         }
+        WD_MARK();
         // (4) retire finished rays: second ray of the item, or hand the slot to the vertex stage
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
@@ -1048,6 +1099,7 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
           qv_count3 += __popcll(m3);
         }
 
+        WD_ADD(wd_ret);
         // (5) leave when a full vertex batch waits, or when nothing is left to walk
         if (qv_count0 >= A.pool_vbatch || qv_count1 >= A.pool_vbatch || qv_count2 >= A.pool_vbatch ||
             qv_count3 >= A.pool_vbatch)
@@ -1089,6 +1141,10 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
         for (int k = 0; k < 6; ++k) atomicAdd(&stats->prof[k], dg->cyc[k]);
         for (int k = 0; k < 4; ++k) atomicAdd(&stats->prof[6 + k], dg->nbatch[k]), atomicAdd(&stats->prof[11 + k], dg->nslots[k]);
         atomicAdd(&stats->prof[10], 1ull);
+#ifdef VIMG_WALK_DIAG
+        const unsigned long long wd[10] = {wd_fill, wd_box, wd_leaf, wd_ret, wd_nbox, wd_boxlanes, wd_nleaf, wd_leaflanes, wd_primtrips, 0};
+        for (int k = 0; k < 9; ++k) atomicAdd(&stats->prof[16 + k], wd[k]);
+#endif
       }
     }
   }

@@ -64,6 +64,8 @@ struct VimgDeviceScene {
   float* d_frame = nullptr;
   void* d_pool_cold = nullptr;   // pooled kernel: cold slot records of every resident wave
   size_t pool_cold_bytes = 0;
+  void* d_stack_ovf = nullptr;   // pool4, deep trees: the stack entries beyond the LDS part, per resident wave
+  size_t stack_ovf_bytes = 0;
   void* d_pool_state = nullptr;  // pooled kernel: per-pixel record between sample segments
   size_t pool_state_bytes = 0;
   uint32_t pool_epoch = 0;       // bumped per launch: tags of earlier launches never match
@@ -240,7 +242,7 @@ void options_from_env(VimgHipOptions* o) {
       {"VIMG_HIP_POOL_BOXMIN", &o->pool_boxmin},       {"VIMG_HIP_LDS_LEAF", &o->lds_leaf},
       {"VIMG_HIP_STAGE_SLOTS", &o->stage_slots},       {"VIMG_HIP_STAGE_SEG_LEN", &o->stage_seg_len},
       {"VIMG_HIP_STAGE_WCHUNK", &o->stage_wchunk},     {"VIMG_HIP_STAGE_WALK_QUOTA", &o->stage_walk_quota},
-      {"VIMG_HIP_POOL4_RAYS", &o->pool4_rays}};
+      {"VIMG_HIP_POOL4_RAYS", &o->pool4_rays},             {"VIMG_HIP_LDS_STACK", &o->lds_stack}};
   for (auto& v : vars)
     if (const char* e = getenv(v.name)) *v.field = atoi(e);
 }
@@ -333,7 +335,7 @@ uint32_t log2_of(uint32_t pow2) {
 // The policy of one launch.  `sched_override`: 0 = by options / policy, else the scheduler to build
 // the configuration for (the fall-back from a scheduler that cannot take this launch).
 LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int sx, int sy,
-                      bool for_render = true, int sched_override = 0) {
+                      bool for_render = true, int sched_override = 0, bool lds_stack_all = false) {
   LaunchCfg c{};
   const VimgHipOptions& o = s->opt;
   const uint64_t items = (sx >= 0) ? 1 : uint64_t(local_tiles(s, p)) * 64u;
@@ -372,11 +374,19 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   a.num_local_tiles = local_tiles(s, p);
   a.full_stats = 0;
   a.stack_entries = s->d.max_depth + 2;
+  a.stack_lds = a.stack_entries;
+  a.stack_ovf = nullptr;
+  // pool4 on trees that do not fit in LDS: the first 12 entries of a lane's stack in LDS, the rest in
+  // global memory (the LDS goes to path slots instead); `lds_stack_all`: second pass, when the tree
+  // turned out to fit (the build without the overflow path)
+  if (sched == VIMG_SCHED_POOL4 && !lds_stack_all)
+    a.stack_lds = std::min(a.stack_entries, std::max(1u, opt_or(o.lds_stack, 32u)));
+  const uint32_t stack_rows = (sched == VIMG_SCHED_POOL4) ? pool4_stack_rows_of(a.stack_entries, a.stack_lds) : a.stack_entries;
   a.single_x = sx;
   a.single_y = sy;
   // LDS budget per 256-thread workgroup: stacks first, then as much of the top of the tree as
   // fits in 40 KiB total (keeps >= 4 workgroups per CU inside the 160 KiB)
-  const uint32_t stack_bytes = 4u * a.stack_entries * 64u * 4u * uint32_t(c.rays);
+  const uint32_t stack_bytes = 4u * stack_rows * 64u * 4u * uint32_t(c.rays);
   // (the pooled and staged kernels spend LDS on path slots / queue chunks instead: they keep the
   // first six levels of the tree, 4 KiB - config 5: 40 KiB budget 1.69, 28 KiB 1.78 Grays/s)
   uint32_t budget = (sched != VIMG_SCHED_LANE) ? std::min(40u * 1024u, stack_bytes + 4608u) : 40u * 1024u;
@@ -393,7 +403,9 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   // config 4 / 5 stand-ins: never 1.02 / 1.74, 8 lanes 1.19 / 2.10, 16: 1.18 / 2.13, 24: 1.20 / 2.13,
   // 40: 1.15 / 1.93 Grays/s
   a.pool_boxmin = std::min(64u, opt_or(o.pool_boxmin, 16u));
+
   c.deep = (sched != VIMG_SCHED_LANE) && a.lds_nodes < s->d.num_nodes;   // the other build reads every node from LDS
+  if (!c.deep && a.stack_lds < a.stack_entries) return make_launch(s, p, sx, sy, for_render, sched_override, true);
   // small scenes: all leaf records in LDS too (they cost a few slots, the walk gains more)
   uint32_t leaf_bytes = 0;
   a.lds_leaf = 0;
@@ -487,6 +499,15 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   return c;
 }
 
+int grow(void** p, size_t* have, size_t need) {
+  if (need <= *have) return VIMG_OK;
+  if (*p) HIP_TRY(hipFree(*p));
+  *p = nullptr;
+  *have = 0;
+  HIP_TRY(hipMalloc(p, need));
+  *have = need;
+  return VIMG_OK;
+}
 // The pooled kernel keeps the cold records of its path slots in global memory: one region per
 // resident wave, owned by the scene and grown on demand (42 MB for config 2 on 256 CUs).
 int ensure_pool(VimgDeviceScene* s, LaunchCfg& c) {
@@ -503,6 +524,12 @@ int ensure_pool(VimgDeviceScene* s, LaunchCfg& c) {
     s->pool_cold_bytes = need;
   }
   c.args.pool_cold = (VIMG_GLOBAL v4u*)s->d_pool_cold;
+  if (c.args.stack_lds < c.args.stack_entries) {
+    if (int rc = grow(&s->d_stack_ovf, &s->stack_ovf_bytes,
+                      size_t(c.grid) * 4u * uint32_t(c.rays) * (c.args.stack_entries - c.args.stack_lds) * 256u))
+      return rc;
+    c.args.stack_ovf = (VIMG_GLOBAL uint32_t*)s->d_stack_ovf;
+  }
   c.args.pool_state = nullptr;
   c.args.pool_epoch = 0;
   if (c.args.pool_segments > 1) {
@@ -531,15 +558,6 @@ int ensure_pool(VimgDeviceScene* s, LaunchCfg& c) {
 // The staged kernel keeps all path state in global memory, owned by the scene and grown on demand:
 // control block, queue rings, ready-pixel ring, per-pixel records, slot records (config 2 on 256
 // CUs: 0.01 + 42 + 8 + 46 + 50 MB).  Counters, rings and the ready-pixel ring are cleared per launch.
-int grow(void** p, size_t* have, size_t need) {
-  if (need <= *have) return VIMG_OK;
-  if (*p) HIP_TRY(hipFree(*p));
-  *p = nullptr;
-  *have = 0;
-  HIP_TRY(hipMalloc(p, need));
-  *have = need;
-  return VIMG_OK;
-}
 int ensure_stage(VimgDeviceScene* s, LaunchCfg& c, hipStream_t st) {
   if (c.sched != VIMG_SCHED_STAGE) return VIMG_OK;
   StageArgs& g = c.stage;
@@ -654,6 +672,11 @@ int fetch_stats(VimgDeviceScene* s, const VimgRenderParams* p, VimgRenderStats* 
       std::fprintf(stderr, "[vimg stage] %-18s %14llu cyc %6.2f %%  batches %10llu  slots/batch %7.2f\n", st_names[k],
                    ds.prof[k], 100.0 * double(ds.prof[k]) / double(total ? total : 1), k < 5 ? ds.prof[6 + k] : 0ull,
                    (k < 5 && ds.prof[6 + k]) ? double(ds.prof[11 + k]) / double(ds.prof[6 + k]) : 0.0);
+#ifdef VIMG_WALK_DIAG
+    static const char* wd_names[9] = {"walk: refill+setup cyc", "walk: box loop cyc", "walk: leaf rounds cyc", "walk: retire cyc",
+                                      "box trips", "box lanes", "leaf rounds", "leaf lanes", "leaf prim trips"};
+    for (int k = 0; k < 9; ++k) std::fprintf(stderr, "[vimg walk] %-24s %14llu\n", wd_names[k], ds.prof[16 + k]);
+#endif
   }
 #endif
 #ifdef VIMG_PROFILE
@@ -981,6 +1004,7 @@ int vimg_hip_scene_free(VimgDeviceScene* s) {
   if (s->d_counter) (void)hipFree(s->d_counter);
   if (s->d_frame) (void)hipFree(s->d_frame);
   if (s->d_pool_cold) (void)hipFree(s->d_pool_cold);
+  if (s->d_stack_ovf) (void)hipFree(s->d_stack_ovf);
   if (s->d_pool_state) (void)hipFree(s->d_pool_state);
   for (void* q : {s->d_stage_ctl, s->d_stage_kargs, s->d_stage_rings, s->d_stage_pix_ring, s->d_stage_pix_state, s->d_stage_slots})
     if (q) (void)hipFree(q);
