@@ -59,8 +59,8 @@ typedef struct VimgHipOptions {
   int32_t pool_segments;      /* POOL: segments a pixel's samples are cut into.  AUTO: ~56 / pool generations, <= 16 */
   int32_t pool_refill;        /* POOL / STAGE walk: finished rays that trigger a refill pass.  AUTO 16 */
   int32_t pool_vbatch;        /* POOL: queued slots of one class that start a vertex batch.  AUTO 64 */
-  int32_t pool_classes;       /* POOL: vertex queues by material, 1..3.  AUTO 3 */
-  int32_t pool_starve;        /* POOL: idle walk lanes that force a partial vertex batch.  AUTO 24 */
+  int32_t pool_classes;       /* POOL: vertex queues by material, 1..3.  AUTO 3; POOL4 on trees beyond LDS: 1 */
+  int32_t pool_starve;        /* POOL: idle walk lanes that force a partial vertex batch.  AUTO 24; POOL4 on trees beyond LDS: 32 */
   int32_t pool_boxmin;        /* POOL / STAGE, deep trees: leave the box loop below this many descending lanes.  AUTO 16 */
   int32_t lds_leaf;           /* POOL / STAGE: 0 = never copy the leaf records to LDS.  AUTO: when they fit 4 KiB */
   int32_t stage_slots;        /* STAGE: path slots in flight.  AUTO: 2 x resident lanes, <= pixels of the launch */

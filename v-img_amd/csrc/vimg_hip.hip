@@ -398,14 +398,20 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   a.pool_slots = 0;
   a.pool_refill = std::max(1u, opt_or(o.pool_refill, 16u));
   a.pool_vbatch = std::min(64u, std::max(1u, opt_or(o.pool_vbatch, 64u)));
-  a.pool_classes = std::min(3u, std::max(1u, opt_or(o.pool_classes, 3u)));
-  a.pool_starve = std::min(64u, std::max(1u, opt_or(o.pool_starve, 24u)));
   // config 4 / 5 stand-ins: never 1.02 / 1.74, 8 lanes 1.19 / 2.10, 16: 1.18 / 2.13, 24: 1.20 / 2.13,
   // 40: 1.15 / 1.93 Grays/s
   a.pool_boxmin = std::min(64u, opt_or(o.pool_boxmin, 16u));
 
   c.deep = (sched != VIMG_SCHED_LANE) && a.lds_nodes < s->d.num_nodes;   // the other build reads every node from LDS
   if (!c.deep && a.stack_lds < a.stack_entries) return make_launch(s, p, sx, sy, for_render, sched_override, true);
+  // Vertex queues and the starvation threshold.  Trees in LDS (pools of 150-190 slots): one queue per
+  // material class, a partial batch when 24 walk lanes idle.  Trees in global memory leave a pool of
+  // about 100 slots, which three class queues drain to 21-27 slots per batch and 20 rays per walk
+  // pass: there ONE queue of shading vertices (next to the finishers') and 32 idle lanes measure best
+  // (stand-ins of configs 4 / 5, 32 spp: 1.60 -> 1.72, 2.68 -> 2.81 Grays/s;
+  // profiles/r2_pool4/deep_policy_sweeps.txt)
+  a.pool_classes = std::min(3u, std::max(1u, opt_or(o.pool_classes, c.deep ? 1u : 3u)));
+  a.pool_starve = std::min(64u, std::max(1u, opt_or(o.pool_starve, c.deep ? 32u : 24u)));
   // small scenes: all leaf records in LDS too (they cost a few slots, the walk gains more)
   uint32_t leaf_bytes = 0;
   a.lds_leaf = 0;
