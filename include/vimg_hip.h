@@ -48,7 +48,8 @@ enum {
   VIMG_SCHED_LANE = 1,   /* render_kernel: one path per lane, persistent waves */
   VIMG_SCHED_POOL = 2,   /* render_pool_kernel: ~240 path slots per wave in LDS, walk + vertex stages in one wave */
   VIMG_SCHED_STAGE = 3,  /* render_stage_kernel: path state in HBM slots, stages coupled by global queues, 4 waves/SIMD */
-  VIMG_SCHED_POOL4 = 4   /* render_pool4_kernel: the pooled scheduler with the vertex stage as calls, 4 waves/SIMD */
+  VIMG_SCHED_POOL4 = 4,  /* render_pool4_kernel: the pooled scheduler with the vertex stage as calls */
+  VIMG_SCHED_POOL4G = 5  /* the same with ONE pool and one set of queues per workgroup (four waves share them under a lock in LDS) */
 };
 typedef struct VimgHipOptions {
   uint32_t struct_size;       /* sizeof(VimgHipOptions): lets the library accept older callers */
@@ -69,6 +70,7 @@ typedef struct VimgHipOptions {
   int32_t stage_walk_quota;   /* STAGE: rays a wave walks before it looks at the queues again.  AUTO 2048 */
   int32_t pool4_rays;         /* reserved (two rays per lane in the walk measured slower; 1 is what runs) */
   int32_t lds_stack;          /* POOL4, trees beyond LDS: entries of a lane's traversal stack kept in LDS, the rest in global memory.  AUTO 32 */
+  int32_t pool_gbreak;        /* POOL4G: a wave leaves the walk for a full vertex batch only with this many rays or fewer in its lanes.  AUTO 32 */
 } VimgHipOptions;
 /* Fills every field with VIMG_OPT_AUTO (and struct_size). */
 void vimg_hip_options_default(VimgHipOptions* opts);

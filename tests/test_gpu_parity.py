@@ -102,6 +102,11 @@ SCHEDULES = {
     "pool4": dict(scheduler="pool4"),
     "pool4/5": dict(scheduler="pool4", pool_segments=5),
     "pool4/4": dict(scheduler="pool4", waves_per_simd=4, pool_segments=3),
+    # one pool and one set of queues per workgroup: the four waves take rays and batches from
+    # shared rings under a lock in LDS; with pixels cut into segments; with few slots per wave
+    "pool4g": dict(scheduler="pool4g"),
+    "pool4g/5": dict(scheduler="pool4g", pool_segments=5),
+    "pool4g/few": dict(scheduler="pool4g", pool_slots=24, pool_segments=2),
     # trees beyond LDS keep only the first entries of a lane's traversal stack in LDS and the rest
     # in global memory: here one entry / three, so that nearly every push and pop takes that path
     "pool4/stack1": dict(scheduler="pool4", lds_stack=1),
@@ -130,7 +135,8 @@ def test_all_schedulers_give_the_same_bits(scene_name):
     for name, opts in SCHEDULES.items():
         d = _dev_opts(s, **opts)
         assert d.kernel.startswith({"lane": "render_kernel", "pool": "render_pool_kernel", "pool4": "render_pool4_kernel",
-                                    "stage": "render_stage_kernel"}[opts["scheduler"]]), (name, d.kernel)
+                                    "pool4g": "render_pool4_kernel", "stage": "render_stage_kernel"}[opts["scheduler"]]), (name, d.kernel)
+        assert ("group" in d.kernel) == (opts["scheduler"] == "pool4g"), (name, d.kernel)
         img, st = d.render_to_host(p)
         again, _ = d.render_to_host(p)            # a second launch on the same records
         assert np.array_equal(img.view(np.uint32), again.view(np.uint32)), name
@@ -171,7 +177,8 @@ def test_pooled_and_staged_schedulers_on_every_feature(case):
     s, kw = mk()
     p = s.default_params(**kw)
     lane, st_lane = _dev_opts(s, scheduler="lane").render_to_host(p)
-    for name in ("pool", "pool/5", "pool4", "pool4/5", "pool4/4", "pool4/stack1", "pool4/stack3", "stage", "stage/few"):
+    for name in ("pool", "pool/5", "pool4", "pool4/5", "pool4/4", "pool4/stack1", "pool4/stack3", "pool4g", "pool4g/5",
+                 "pool4g/few", "stage", "stage/few"):
         d = _dev_opts(s, **SCHEDULES[name])
         img, st = d.render_to_host(p)
         assert np.array_equal(img.view(np.uint32), lane.view(np.uint32)), (case, name, d.kernel)

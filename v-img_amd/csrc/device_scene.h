@@ -127,6 +127,7 @@ struct RenderArgs {
   uint32_t pool_vbatch;             // pooled kernel: queued slots of one class that start a vertex batch
   uint32_t pool_boxmin;             // pooled kernel: leave the box loop when fewer lanes than this still descend (0 = never)
   uint32_t pool_starve;             // pooled kernel: idle walk lanes (with no ray queued) that force a partial vertex batch
+  uint32_t pool_gbreak;             // pool4 group build: a wave leaves the walk for a full batch only with this many rays or fewer in its lanes
   uint32_t pool_classes;            // pooled kernel: vertex queues: 1 = one, 2 = Principled apart, 3 = + Lambertian apart
   int32_t single_x, single_y;       // trace_pixel mode when >= 0
 };

@@ -41,6 +41,7 @@ __global__ void pool4_args_kernel(const Pool4KArgs ka, Pool4KArgs* __restrict__ 
   if (threadIdx.x == 0 && blockIdx.x == 0) *dst = ka;
 }
 
+constexpr uint32_t P4_HOT = 3u;                      // hot records of a slot in LDS: SR_ORIGIN, SR_RAY, SR_SHADOW
 // wave-uniform scheduler state, one record per wave in LDS: what the kernel's main loop and the
 // vertex-stage calls both read and write
 struct Pool4Wave {
@@ -50,6 +51,63 @@ struct Pool4Wave {
   uint32_t pad[2];
 };
 static_assert(sizeof(Pool4Wave) == 64, "Pool4Wave is one 64-byte record");
+// GRP builds: the four waves of a workgroup share ONE pool of 4 x pool_slots slots and one set of
+// queues (16-bit slot ids).  Every queue operation of a wave - taking rays, handing finished ones to
+// the vertex queues, taking a batch, handing its slots back - runs under the group's lock; the
+// record below holds what the per-wave record holds in the other builds.
+struct Pool4Group {
+  uint32_t lock, live, pixels_left, abort;   // live: slots that have not retired
+  uint32_t qw_head, qw_count;
+  uint32_t qv_head[4], qv_count[4];
+  uint32_t pad[2];
+};
+static_assert(sizeof(Pool4Group) == 64, "Pool4Group is one 64-byte record");
+constexpr uint32_t P4G_LDS_BYTES = 3u * 16u + 4u + 5u * 2u;   // hot records, primitive id, five 16-bit rings
+VD uint32_t lds_aload(VIMG_LDS uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// Lock of the group's queue state: lane 0 spins (with a bound: a wave that cannot get it within
+// seconds raises the launch's error word and the group's abort flag instead of hanging the GPU).
+VD void grp_lock(VIMG_LDS Pool4Group* G, unsigned int* err_word) {
+  if ((threadIdx.x & 63u) == 0u) {
+    uint32_t spins = 0;
+    for (;;) {
+      uint32_t expect = 0u;
+      if (__hip_atomic_compare_exchange_strong(&G->lock, &expect, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP))
+        break;
+      if (++spins > (1u << 22)) {
+        atomicOr(err_word, 2u);
+        __hip_atomic_store(&G->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+VD void grp_unlock(VIMG_LDS Pool4Group* G) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(&G->lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// where the shared tables of a group live behind its slot records (pool = first record, PS slots)
+struct Pool4GLayout {
+  VIMG_LDS uint32_t* q_prim;
+  VIMG_LDS uint16_t* q_walk;
+  VIMG_LDS uint16_t* q_vertex;   // four rings of capacity PS
+  VIMG_LDS Pool4Group* G;
+  VIMG_LDS uint16_t* bslots;     // [wave][64]: the slots of the batch a wave has taken
+};
+VD Pool4GLayout pool4g_layout(VIMG_LDS uint32_t* pool, uint32_t PS) {
+  Pool4GLayout l;
+  l.q_prim = pool + P4_HOT * 4u * PS;
+  l.q_walk = reinterpret_cast<VIMG_LDS uint16_t*>(l.q_prim + PS);
+  l.q_vertex = l.q_walk + PS;
+  l.G = reinterpret_cast<VIMG_LDS Pool4Group*>(l.q_vertex + 4u * PS);   // PS is a multiple of 8: 16-byte aligned
+  l.bslots = reinterpret_cast<VIMG_LDS uint16_t*>(l.G + 1);
+  return l;
+}
+__host__ __device__ constexpr uint32_t pool4g_group_bytes(uint32_t slots_per_wave) {
+  return P4G_LDS_BYTES * 4u * slots_per_wave + 64u + 4u * 64u * 2u;
+}
 // rows of a lane's LDS stack: all entries, or the first stack_lds and one more that takes the
 // writes of the entries kept in global memory
 __host__ __device__ constexpr uint32_t pool4_stack_rows_of(uint32_t entries, uint32_t in_lds) { return in_lds < entries ? in_lds + 1u : entries; }
@@ -64,7 +122,6 @@ struct Pool4Diag {
 // (one more 16-byte read and write per vertex batch and slot; 57 instead of 73 LDS bytes per slot
 // = 28 % more slots, and the slot count is what this scheduler's rate hangs on: 64 slots 6.1,
 // 80: 8.1, 102: 9.7 Grays/s on config 2 at four waves per SIMD).
-constexpr uint32_t P4_HOT = 3u;                      // SR_ORIGIN, SR_RAY, SR_SHADOW
 constexpr uint32_t P4_LDS_BYTES = P4_HOT * 16u + 4u + 5u;
 // Cold records of a slot: the four every vertex batch reads and writes are ONE aligned 64-byte
 // line, [slot][4] (throughput, result, NEE term, RNG); the pixel accumulator (finisher batches
@@ -83,9 +140,11 @@ VD uint32_t uni(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_read
 // (WPS: the register budget of the kernel that calls it - a copy per budget, so that the three-wave
 // build's callees get its 168 registers: 104 of them are caller-saved, and a callee that stays
 // within those saves nothing - 8 to 29 saved registers per call instead of 32 to 48)
-template <bool TEX, bool FIN, int MTC, int WPS>
+// GRP: the slots and queues are the workgroup's (Pool4Group); `n_in` slots of the batch wait in the
+// wave's row of `bslots`.
+template <bool TEX, bool FIN, int MTC, int WPS, bool GRP>
 __device__ __noinline__ void pool4_vertex(uint32_t k_lo, uint32_t k_hi, VIMG_LDS uint32_t* pool,
-                                          VIMG_LDS Pool4Wave* pw, uint32_t cls) {
+                                          VIMG_LDS Pool4Wave* pw, uint32_t cls, uint32_t n_in) {
   const Pool4KPtr K = pool4_kargs(k_lo, k_hi);
   const DScene& g = *(const DScene*)&K->g;
   const RenderArgs& A = *(const RenderArgs*)&K->A;
@@ -100,17 +159,21 @@ __device__ __noinline__ void pool4_vertex(uint32_t k_lo, uint32_t k_hi, VIMG_LDS
   const uint32_t total_claims = total_items * n_seg;
   constexpr uint32_t roulette_threshold = 5;
   const bool material_mode = (A.integrator == VIMG_INTEGRATOR_MATERIAL);
-  const uint32_t P = A.pool_slots;
-  // cold region of this wave: [slot][4] main lines, then the accumulator plane, then the cone plane
-  // (P is even, so every wave's region starts on a 64-byte boundary)
-  VIMG_GLOBAL v4u* cold = A.pool_cold + (size_t(blockIdx.x) * 4u + wave) * (size_t(pool4_cold_records(TEX)) * P);
+  const uint32_t P = GRP ? 4u * A.pool_slots : A.pool_slots;   // slots of the pool this batch belongs to
+  // cold region of this wave (GRP: of this workgroup): [slot][4] main lines, then the accumulator
+  // plane, then the cone plane (P is even, so every region starts on a 64-byte boundary)
+  VIMG_GLOBAL v4u* cold = A.pool_cold + (GRP ? size_t(blockIdx.x) : size_t(blockIdx.x) * 4u + wave) *
+                                            (size_t(pool4_cold_records(TEX)) * P);
   VIMG_GLOBAL v4u* cold_acc = cold + size_t(SC4_MAIN) * P;
   [[maybe_unused]] VIMG_GLOBAL v4u* cold_cone = cold_acc + P;
   auto crd = [&](uint32_t r, uint32_t slot) -> v4u { return cold[slot * SC4_MAIN + r]; };
   auto cwr = [&](uint32_t r, uint32_t slot, v4u v) { cold[slot * SC4_MAIN + r] = v; };
+  using QId = std::conditional_t<GRP, uint16_t, uint8_t>;
   VIMG_LDS uint32_t* q_prim = pool + P4_HOT * 4u * P;
-  VIMG_LDS uint8_t* q_walk = reinterpret_cast<VIMG_LDS uint8_t*>(q_prim + P);
-  VIMG_LDS uint8_t* q_vertex = q_walk + P;
+  VIMG_LDS QId* q_walk = reinterpret_cast<VIMG_LDS QId*>(q_prim + P);
+  VIMG_LDS QId* q_vertex = q_walk + P;
+  [[maybe_unused]] VIMG_LDS Pool4Group* G = reinterpret_cast<VIMG_LDS Pool4Group*>(q_vertex + 4u * P);   // (GRP layout)
+  [[maybe_unused]] VIMG_LDS uint16_t* bslots = reinterpret_cast<VIMG_LDS uint16_t*>(G + 1) + wave * 64u;
   VIMG_LDS v4u* recs = reinterpret_cast<VIMG_LDS v4u*>(pool);
   auto rd = [&](uint32_t r, uint32_t slot) -> v4u { return recs[r * P + slot]; };
   auto wr = [&](uint32_t r, uint32_t slot, v4u v) { recs[r * P + slot] = v; };
@@ -123,14 +186,18 @@ __device__ __noinline__ void pool4_vertex(uint32_t k_lo, uint32_t k_hi, VIMG_LDS
   constexpr bool finisher_batch = FIN;
 
   // scheduler state of the wave
-  uint32_t qw_head = uni(pw->qw_head), qw_count = uni(pw->qw_count);
-  uint32_t qv_head0 = uni(pw->qv_head[0]), qv_count0 = uni(pw->qv_count[0]);
-  bool pixels_left = uni(pw->pixels_left) != 0u, skip_fin = uni(pw->skip_fin) != 0u;
+  uint32_t qw_head = GRP ? 0u : uni(pw->qw_head), qw_count = GRP ? 0u : uni(pw->qw_count);
+  uint32_t qv_head0 = GRP ? 0u : uni(pw->qv_head[0]), qv_count0 = GRP ? 0u : uni(pw->qv_count[0]);
+  bool pixels_left = (GRP ? uni(lds_aload(&G->pixels_left)) : uni(pw->pixels_left)) != 0u, skip_fin = uni(pw->skip_fin) != 0u;
   uint32_t idle_polls = uni(pw->idle_polls);
   uint32_t nan_here = 0;
   uint32_t n, slot;
   bool on;
-  {
+  if constexpr (GRP) {
+    n = uni(n_in);
+    on = lane < n;
+    slot = on ? bslots[lane] : 0u;
+  } else {
     const uint32_t qv_count = uni(pw->qv_count[cls]), qv_head = uni(pw->qv_head[cls]);
     n = qv_count < 64u ? qv_count : 64u;
     on = lane < n;
@@ -597,16 +664,34 @@ __device__ __noinline__ void pool4_vertex(uint32_t k_lo, uint32_t k_hi, VIMG_LDS
   {
     const bool to_walk = keep && (has_s || has_r), to_fin = keep && !to_walk;
     const unsigned long long mask = __ballot(to_walk), mfin = __ballot(to_fin);
-    if (to_walk) q_walk[ring(qw_head + qw_count + lane_rank(mask, lane))] = static_cast<uint8_t>(slot);
-    if (to_fin) q_vertex[ring(qv_head0 + qv_count0 + lane_rank(mfin, lane))] = static_cast<uint8_t>(slot);
+    if constexpr (GRP) {
+      grp_lock(G, work_counter + 1);
+      qw_head = uni(G->qw_head), qw_count = uni(G->qw_count);
+      qv_head0 = uni(G->qv_head[0]), qv_count0 = uni(G->qv_count[0]);
+    }
+    if (to_walk) q_walk[ring(qw_head + qw_count + lane_rank(mask, lane))] = static_cast<QId>(slot);
+    if (to_fin) q_vertex[ring(qv_head0 + qv_count0 + lane_rank(mfin, lane))] = static_cast<QId>(slot);
     qw_count += __popcll(mask);
     qv_count0 += __popcll(mfin);
+    if constexpr (GRP) {
+      if (lane == 0) {
+        G->qw_count = qw_count, G->qv_count[0] = qv_count0;
+        if (!pixels_left) G->pixels_left = 0u;
+      }
+      grp_unlock(G);
+      const uint32_t n_retired = static_cast<uint32_t>(__popcll(__ballot(on && retire)));
+      if (n_retired && lane == 0)
+        __hip_atomic_fetch_sub(&G->live, n_retired, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
   }
   // scheduler state back to the wave's record
   if (lane == 0) {
-    pw->qw_head = qw_head, pw->qw_count = qw_count;
-    pw->qv_head[0] = qv_head0, pw->qv_count[0] = qv_count0;
-    pw->pixels_left = pixels_left ? 1u : 0u, pw->skip_fin = skip_fin ? 1u : 0u;
+    if constexpr (!GRP) {
+      pw->qw_head = qw_head, pw->qw_count = qw_count;
+      pw->qv_head[0] = qv_head0, pw->qv_count[0] = qv_count0;
+      pw->pixels_left = pixels_left ? 1u : 0u;
+    }
+    pw->skip_fin = skip_fin ? 1u : 0u;
     pw->idle_polls = idle_polls;
   }
   if (__any(nan_here != 0u)) {
@@ -618,9 +703,11 @@ __device__ __noinline__ void pool4_vertex(uint32_t k_lo, uint32_t k_hi, VIMG_LDS
 // NC: rays a lane walks at the same time (1 or 2).  With two, the box loop tests the node of each
 // in one pass - twice the independent arithmetic and twice the loads in flight per trip, which is
 // what a walk that waits for its node records (LDS on small scenes, L2 / HBM on large ones) lacks.
-template <bool TEX, bool DEEP, int WPS, int NC>
+// GRP: one pool and one set of queues per workgroup instead of per wave (Pool4Group).
+template <bool TEX, bool DEEP, int WPS, int NC, bool GRP>
 __global__ void __launch_bounds__(256, WPS)
 render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
+  static_assert(!GRP || NC == 1, "the group build walks one ray per lane");
   const uint32_t k_lo = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(kargs)),
                  k_hi = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(kargs) >> 32);
   const Pool4KPtr K = pool4_kargs(k_lo, k_hi);
@@ -642,31 +729,44 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
   const uint32_t total_claims = total_items * n_seg;
   constexpr uint32_t roulette_threshold = 5;
   const bool material_mode = (A.integrator == VIMG_INTEGRATOR_MATERIAL);
-  const uint32_t P = A.pool_slots;
-  // LDS carve-out of this wave behind the node planes and the four traversal stacks
+  const uint32_t P = GRP ? 4u * A.pool_slots : A.pool_slots;   // slots of the pool this wave works on
+  using QId = std::conditional_t<GRP, uint16_t, uint8_t>;
+  // LDS carve-out of this wave (GRP: of the workgroup) behind the node planes and the four traversal stacks
   VIMG_LDS uint32_t* pool;
-  VIMG_LDS uint8_t* q_walk;
+  VIMG_LDS QId* q_walk;
   VIMG_LDS v4f* lds_leaf;        // copy of leaf_prims (all of them) when A.lds_leaf != 0
   VIMG_LDS uint32_t* q_prim;     // primitive id of the hit, per slot
-  VIMG_LDS uint8_t* q_vertex;    // four rings of capacity P: class 0 finishers, 1 Lambertian (+rest), 2 Principled, 3 other
+  VIMG_LDS QId* q_vertex;        // four rings of capacity P: class 0 finishers, 1 Lambertian (+rest), 2 Principled, 3 other
   VIMG_LDS Pool4Wave* pw;
   VIMG_LDS Pool4Diag* dg;
+  [[maybe_unused]] VIMG_LDS Pool4Group* G = nullptr;
+  [[maybe_unused]] VIMG_LDS uint16_t* bslots = nullptr;   // this wave's row
   VIMG_LDS uint32_t* stack0;   // this lane's stack of its first ray: entry k at stack0[k * 64]; second ray: + stack_entries * 64
   {
     const uint32_t node_bytes = (lds_node_bytes(A.lds_nodes) + 255u) & ~255u;
     const uint32_t stack_bytes = 4u * uint32_t(NC) * pool4_stack_rows_of(A.stack_entries, A.stack_lds) * 64u * 4u;   // [wave][ray of the lane][entry][lane]
     stack0 = reinterpret_cast<VIMG_LDS uint32_t*>((VIMG_LDS unsigned char*)lds_raw + node_bytes) +
              size_t(wave) * NC * pool4_stack_rows_of(A.stack_entries, A.stack_lds) * 64u + lane;
-    const uint32_t per_wave = pool4_wave_bytes(P) / 4u;   // in dwords
     VIMG_LDS uint32_t* base =
         reinterpret_cast<VIMG_LDS uint32_t*>((VIMG_LDS unsigned char*)lds_raw + node_bytes + stack_bytes);
-    pool = base + wave * per_wave;
-    q_prim = pool + P4_HOT * 4u * P;
-    q_walk = reinterpret_cast<VIMG_LDS uint8_t*>(q_prim + P);
-    q_vertex = q_walk + P;
-    pw = reinterpret_cast<VIMG_LDS Pool4Wave*>(base + 4u * per_wave) + wave;
-    dg = reinterpret_cast<VIMG_LDS Pool4Diag*>(base + 4u * per_wave + 4u * (sizeof(Pool4Wave) / 4u)) + wave;
-    lds_leaf = reinterpret_cast<VIMG_LDS v4f*>(base + 4u * per_wave + 4u * ((sizeof(Pool4Wave) + sizeof(Pool4Diag)) / 4u));
+    VIMG_LDS uint32_t* tail;   // behind the pools: per-wave records, leaf copy
+    if constexpr (GRP) {
+      pool = base;
+      const Pool4GLayout lay = pool4g_layout(pool, P);
+      q_prim = lay.q_prim, q_walk = lay.q_walk, q_vertex = lay.q_vertex, G = lay.G;
+      bslots = lay.bslots + wave * 64u;
+      tail = base + pool4g_group_bytes(A.pool_slots) / 4u;
+    } else {
+      const uint32_t per_wave = pool4_wave_bytes(P) / 4u;   // in dwords
+      pool = base + wave * per_wave;
+      q_prim = pool + P4_HOT * 4u * P;
+      q_walk = reinterpret_cast<VIMG_LDS QId*>(q_prim + P);
+      q_vertex = q_walk + P;
+      tail = base + 4u * per_wave;
+    }
+    pw = reinterpret_cast<VIMG_LDS Pool4Wave*>(tail) + wave;
+    dg = reinterpret_cast<VIMG_LDS Pool4Diag*>(tail + 4u * (sizeof(Pool4Wave) / 4u)) + wave;
+    lds_leaf = reinterpret_cast<VIMG_LDS v4f*>(tail + 4u * ((sizeof(Pool4Wave) + sizeof(Pool4Diag)) / 4u));
     if (lane < sizeof(Pool4Diag) / 4u) reinterpret_cast<VIMG_LDS uint32_t*>(dg)[lane] = 0u;
     for (uint32_t i = threadIdx.x; i < A.lds_leaf * 3u; i += blockDim.x)
       lds_leaf[i] = reinterpret_cast<gptr<v4f>>(g.leaf_prims)[i];
@@ -693,13 +793,28 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
   auto ring = [&](uint32_t i) { return i >= P ? i - P : i; };
 
   // every slot starts "fresh": it needs a pixel
-  for (uint32_t s = lane; s < P; s += 64) {
-    word(SR_RAY, 3, s) = SF_FRESH;
-    q_vertex[s] = static_cast<uint8_t>(s);
+  if constexpr (GRP) {
+    for (uint32_t s = threadIdx.x; s < P; s += 256) {
+      word(SR_RAY, 3, s) = SF_FRESH;
+      q_vertex[s] = static_cast<QId>(s);
+    }
+    if (threadIdx.x == 0) {
+      G->lock = 0u, G->live = P, G->pixels_left = 1u, G->abort = 0u;
+      G->qw_head = 0u, G->qw_count = 0u;
+      for (int k = 0; k < 4; ++k) G->qv_head[k] = 0u, G->qv_count[k] = (k == 0) ? P : 0u;
+    }
+    if (lane == 0) pw->skip_fin = 0u, pw->idle_polls = 0u;
+    __syncthreads();
+  } else {
+    for (uint32_t s = lane; s < P; s += 64) {
+      word(SR_RAY, 3, s) = SF_FRESH;
+      q_vertex[s] = static_cast<QId>(s);
+    }
   }
   qv_count0 = P;
   bool skip_fin = false;
   uint32_t idle_polls = 0;
+  [[maybe_unused]] uint32_t idle_wait = 0;   // GRP: looks at empty queues while other waves of the group hold the slots
   if (lane == 0) pw->pixels_left = 1u, pw->nan_samples = 0u;
 
   // ---- persistent walk registers of the lane: NC rays
@@ -751,6 +866,11 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
 #define WD_ADD(acc) ((void)0)
 #endif
   for (;;) {
+    if constexpr (GRP) {   // a look at the group's counters (decisions below are re-made under the lock)
+      qw_count = uni(lds_aload(&G->qw_count));
+      qv_count0 = uni(lds_aload(&G->qv_count[0])), qv_count1 = uni(lds_aload(&G->qv_count[1]));
+      qv_count2 = uni(lds_aload(&G->qv_count[2])), qv_count3 = uni(lds_aload(&G->qv_count[3]));
+    }
     const uint32_t n_walking = count_ctx([](const WalkCtx& c) { return c.slot != SLOT_IDLE; });
     const bool inflight = n_walking != 0u;
     // vertex batches are sorted by the material class of the hit (known from the primitive at the
@@ -764,7 +884,27 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
     // pool_starve or more idle lanes (the walk would go on half empty while slots wait here)
     const bool run_vertex = (qv_max >= A.pool_vbatch) ||
                             (qv_max > 0u && qw_count == 0u && 64u * NC - n_walking >= A.pool_starve * NC);
-    if (!run_vertex && qw_count == 0u && !inflight) {
+    if constexpr (GRP) {
+      if (!run_vertex && qw_count == 0u && !inflight) {
+        // nothing for this wave: done when every slot of the group has retired; else the other
+        // waves hold the slots (in their lanes or in a batch), or the finisher queue holds only
+        // slots that wait for a segment - look again shortly (both waits are bounded, as below)
+        if (uni(lds_aload(&G->live)) == 0u || uni(lds_aload(&G->abort)) != 0u) break;
+        const bool only_waiting = skip_fin && qv_count0 != 0u;
+        skip_fin = false;
+        if ((only_waiting && ++idle_polls > (1u << 20)) || ++idle_wait > (1u << 25)) {
+          if (lane == 0) {
+            atomicOr(work_counter + 1, 1u);
+            __hip_atomic_store(&G->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          break;
+        }
+        __builtin_amdgcn_s_sleep(16);
+        continue;
+      }
+      idle_wait = 0;
+    }
+    if (!GRP && !run_vertex && qw_count == 0u && !inflight) {
       if (!skip_fin || qv_count0 == 0u) break;   // every queue is empty: all done
       skip_fin = false;                          // only waiting slots are left: look at them again
       // Watchdog: the wait is for segments other waves are working on, i.e. for at most the time
@@ -782,29 +922,51 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
 
     if (run_vertex) {
       // ================================================================== VERTEX stage (a call)
-      const uint32_t cls = (qv_elig0 == qv_max) ? 0u : (qv_count1 == qv_max ? 1u : (qv_count2 == qv_max ? 2u : 3u));
+      uint32_t cls = (qv_elig0 == qv_max) ? 0u : (qv_count1 == qv_max ? 1u : (qv_count2 == qv_max ? 2u : 3u));
+      uint32_t n_batch = qv_max < 64u ? qv_max : 64u;
+      if constexpr (GRP) {
+        // take the batch under the lock, from the queue that is fullest NOW (another wave may have
+        // taken what the look above saw)
+        grp_lock(G, work_counter + 1);
+        const uint32_t c0 = skip_fin ? 0u : uni(G->qv_count[0]), c1 = uni(G->qv_count[1]), c2 = uni(G->qv_count[2]),
+                       c3 = uni(G->qv_count[3]);
+        const uint32_t m01 = c0 > c1 ? c0 : c1, m23 = c2 > c3 ? c2 : c3, mx = m01 > m23 ? m01 : m23;
+        cls = (c0 == mx) ? 0u : (c1 == mx ? 1u : (c2 == mx ? 2u : 3u));
+        n_batch = mx < 64u ? mx : 64u;
+        if (n_batch != 0u) {
+          const uint32_t head = uni(G->qv_head[cls]), have = uni(G->qv_count[cls]);
+          if (lane < n_batch) bslots[lane] = q_vertex[cls * P + ring(head + lane)];
+          if (lane == 0) G->qv_head[cls] = ring(head + n_batch), G->qv_count[cls] = have - n_batch;
+        }
+        grp_unlock(G);
+        if (n_batch == 0u) continue;
+      }
       if (full_stats) {
         const unsigned long long now = __builtin_readcyclecounter();
-        if (lane == 0) dg->cyc[4] += now - t_mark, dg->nbatch[cls] += 1, dg->nslots[cls] += (qv_max < 64u ? qv_max : 64u);
+        if (lane == 0) dg->cyc[4] += now - t_mark, dg->nbatch[cls] += 1, dg->nslots[cls] += n_batch;
         t_mark = now;
       }
       if (lane == 0) {
-        pw->qw_head = qw_head, pw->qw_count = qw_count;
-        pw->qv_head[0] = qv_head0, pw->qv_head[1] = qv_head1, pw->qv_head[2] = qv_head2, pw->qv_head[3] = qv_head3;
-        pw->qv_count[0] = qv_count0, pw->qv_count[1] = qv_count1, pw->qv_count[2] = qv_count2, pw->qv_count[3] = qv_count3;
+        if constexpr (!GRP) {
+          pw->qw_head = qw_head, pw->qw_count = qw_count;
+          pw->qv_head[0] = qv_head0, pw->qv_head[1] = qv_head1, pw->qv_head[2] = qv_head2, pw->qv_head[3] = qv_head3;
+          pw->qv_count[0] = qv_count0, pw->qv_count[1] = qv_count1, pw->qv_count[2] = qv_count2, pw->qv_count[3] = qv_count3;
+        }
         pw->skip_fin = skip_fin ? 1u : 0u, pw->idle_polls = idle_polls;
       }
       if (cls == 0u)
-        pool4_vertex<TEX, true, -1, WPS>(k_lo, k_hi, pool, pw, cls);
+        pool4_vertex<TEX, true, -1, WPS, GRP>(k_lo, k_hi, pool, pw, cls, n_batch);
       else if (cls == 1u && A.pool_classes == 3u)
-        pool4_vertex<TEX, false, int(VIMG_MAT_LAMBERTIAN), WPS>(k_lo, k_hi, pool, pw, cls);
+        pool4_vertex<TEX, false, int(VIMG_MAT_LAMBERTIAN), WPS, GRP>(k_lo, k_hi, pool, pw, cls, n_batch);
       else if (cls == 2u && A.pool_classes == 3u)
-        pool4_vertex<TEX, false, int(VIMG_MAT_PRINCIPLED), WPS>(k_lo, k_hi, pool, pw, cls);
+        pool4_vertex<TEX, false, int(VIMG_MAT_PRINCIPLED), WPS, GRP>(k_lo, k_hi, pool, pw, cls, n_batch);
       else
-        pool4_vertex<TEX, false, -1, WPS>(k_lo, k_hi, pool, pw, cls);
-      qw_head = uni(pw->qw_head), qw_count = uni(pw->qw_count);
-      qv_head0 = uni(pw->qv_head[0]), qv_head1 = uni(pw->qv_head[1]), qv_head2 = uni(pw->qv_head[2]), qv_head3 = uni(pw->qv_head[3]);
-      qv_count0 = uni(pw->qv_count[0]), qv_count1 = uni(pw->qv_count[1]), qv_count2 = uni(pw->qv_count[2]), qv_count3 = uni(pw->qv_count[3]);
+        pool4_vertex<TEX, false, -1, WPS, GRP>(k_lo, k_hi, pool, pw, cls, n_batch);
+      if constexpr (!GRP) {
+        qw_head = uni(pw->qw_head), qw_count = uni(pw->qw_count);
+        qv_head0 = uni(pw->qv_head[0]), qv_head1 = uni(pw->qv_head[1]), qv_head2 = uni(pw->qv_head[2]), qv_head3 = uni(pw->qv_head[3]);
+        qv_count0 = uni(pw->qv_count[0]), qv_count1 = uni(pw->qv_count[1]), qv_count2 = uni(pw->qv_count[2]), qv_count3 = uni(pw->qv_count[3]);
+      }
       skip_fin = uni(pw->skip_fin) != 0u, idle_polls = uni(pw->idle_polls);
       if (full_stats) {
         const unsigned long long now = __builtin_readcyclecounter();
@@ -828,7 +990,16 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
             base[k] = n_idle;
             n_idle += static_cast<uint32_t>(__popcll(m[k]));
           }
-          const uint32_t take = n_idle < qw_count ? n_idle : qw_count;
+          bool locked = false;
+          if constexpr (GRP) {
+            qw_count = uni(lds_aload(&G->qw_count));
+            if (n_idle != 0u && qw_count != 0u) {
+              grp_lock(G, work_counter + 1);
+              locked = true;
+              qw_head = uni(G->qw_head), qw_count = uni(G->qw_count);
+            }
+          }
+          const uint32_t take = (GRP && !locked) ? 0u : (n_idle < qw_count ? n_idle : qw_count);
           if (take) {
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
@@ -842,6 +1013,12 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
             }
             qw_head = ring(qw_head + take);
             qw_count -= take;
+          }
+          if constexpr (GRP) {
+            if (locked) {
+              if (take && lane == 0) G->qw_head = qw_head, G->qw_count = qw_count;
+              grp_unlock(G);
+            }
           }
         }
         // (2) ray set-up (reference include/bvh.h:109-143): everything derived from the ray alone
@@ -1085,8 +1262,19 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
                                    m1 = __ballot(done_item && cls == 1),
                                    m2 = __ballot(done_item && cls == 2),
                                    m3 = __ballot(done_item && cls == 3);
+          const bool any_done = (m0 | m1 | m2 | m3) != 0ull;
+          if constexpr (GRP) {
+            if (any_done) {
+              grp_lock(G, work_counter + 1);
+              qv_head0 = uni(G->qv_head[0]), qv_head1 = uni(G->qv_head[1]), qv_head2 = uni(G->qv_head[2]), qv_head3 = uni(G->qv_head[3]);
+              qv_count0 = uni(G->qv_count[0]), qv_count1 = uni(G->qv_count[1]), qv_count2 = uni(G->qv_count[2]), qv_count3 = uni(G->qv_count[3]);
+            } else {
+              qv_count0 = uni(lds_aload(&G->qv_count[0])), qv_count1 = uni(lds_aload(&G->qv_count[1]));
+              qv_count2 = uni(lds_aload(&G->qv_count[2])), qv_count3 = uni(lds_aload(&G->qv_count[3]));
+            }
+          }
           if (done_item) {
-            const uint8_t id = static_cast<uint8_t>(c.slot);
+            const QId id = static_cast<QId>(c.slot);
             if (cls == 0) q_vertex[ring(qv_head0 + qv_count0 + lane_rank(m0, lane))] = id;
             else if (cls == 1) q_vertex[P + ring(qv_head1 + qv_count1 + lane_rank(m1, lane))] = id;
             else if (cls == 2) q_vertex[2 * P + ring(qv_head2 + qv_count2 + lane_rank(m2, lane))] = id;
@@ -1097,13 +1285,39 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
           qv_count1 += __popcll(m1);
           qv_count2 += __popcll(m2);
           qv_count3 += __popcll(m3);
+          if constexpr (GRP) {
+            if (any_done) {
+              if (lane == 0) G->qv_count[0] = qv_count0, G->qv_count[1] = qv_count1, G->qv_count[2] = qv_count2, G->qv_count[3] = qv_count3;
+              // while the lock is held: the lanes that have just come free take queued rays (the
+              // refill at the head of the next round then finds nothing to do and takes no lock)
+              const unsigned long long mi = __ballot(c.slot == SLOT_IDLE);
+              qw_head = uni(G->qw_head), qw_count = uni(G->qw_count);
+              const uint32_t n_idle = static_cast<uint32_t>(__popcll(mi));
+              const uint32_t take = n_idle < qw_count ? n_idle : qw_count;
+              if (take) {
+                const uint32_t r = lane_rank(mi, lane);
+                if (c.slot == SLOT_IDLE && r < take) {
+                  c.slot = q_walk[ring(qw_head + r)];
+                  c.flags = word(SR_RAY, 3, c.slot);
+                  c.phase = (c.flags & SF_HAS_S) ? 0u : 1u;
+                  c.setup = true;
+                }
+                qw_head = ring(qw_head + take), qw_count -= take;
+                if (lane == 0) G->qw_head = qw_head, G->qw_count = qw_count;
+              }
+              grp_unlock(G);
+            }
+          }
         }
+        if constexpr (GRP) qw_count = uni(lds_aload(&G->qw_count));
 
         WD_ADD(wd_ret);
         // (5) leave when a full vertex batch waits, or when nothing is left to walk
         if (qv_count0 >= A.pool_vbatch || qv_count1 >= A.pool_vbatch || qv_count2 >= A.pool_vbatch ||
-            qv_count3 >= A.pool_vbatch)
-          break;
+            qv_count3 >= A.pool_vbatch) {
+          // (GRP: the full batch is the group's; a wave whose lanes are busy leaves it to one that is not)
+          if (!GRP || count_ctx([](const WalkCtx& c) { return c.slot != SLOT_IDLE; }) <= A.pool_gbreak) break;
+        }
         if (qw_count == 0u) {
           const uint32_t walking = count_ctx([](const WalkCtx& c) { return c.slot != SLOT_IDLE; });
           if (walking == 0u) break;

@@ -232,7 +232,7 @@ void options_from_env(VimgHipOptions* o) {
   if (const char* e = getenv("VIMG_HIP_SCHED")) {
     const std::string v(e);
     o->scheduler = v == "lane" ? VIMG_SCHED_LANE : v == "pool" ? VIMG_SCHED_POOL : v == "stage" ? VIMG_SCHED_STAGE
-                 : v == "pool4" ? VIMG_SCHED_POOL4 : atoi(e);
+                 : v == "pool4" ? VIMG_SCHED_POOL4 : v == "pool4g" ? VIMG_SCHED_POOL4G : atoi(e);
   }
   struct { const char* name; int32_t* field; } vars[] = {
       {"VIMG_HIP_WAVES_PER_SIMD", &o->waves_per_simd}, {"VIMG_HIP_LDS_BUDGET_KB", &o->lds_budget_kb},
@@ -242,7 +242,8 @@ void options_from_env(VimgHipOptions* o) {
       {"VIMG_HIP_POOL_BOXMIN", &o->pool_boxmin},       {"VIMG_HIP_LDS_LEAF", &o->lds_leaf},
       {"VIMG_HIP_STAGE_SLOTS", &o->stage_slots},       {"VIMG_HIP_STAGE_SEG_LEN", &o->stage_seg_len},
       {"VIMG_HIP_STAGE_WCHUNK", &o->stage_wchunk},     {"VIMG_HIP_STAGE_WALK_QUOTA", &o->stage_walk_quota},
-      {"VIMG_HIP_POOL4_RAYS", &o->pool4_rays},             {"VIMG_HIP_LDS_STACK", &o->lds_stack}};
+      {"VIMG_HIP_POOL4_RAYS", &o->pool4_rays},             {"VIMG_HIP_LDS_STACK", &o->lds_stack},
+      {"VIMG_HIP_POOL_GBREAK", &o->pool_gbreak}};
   for (auto& v : vars)
     if (const char* e = getenv(v.name)) *v.field = atoi(e);
 }
@@ -276,14 +277,15 @@ struct LaunchCfg {
   int sched;     // VIMG_SCHED_* of this launch
   bool pooled;   // render_pool_kernel for this launch
   int wps;       // register-budget build (waves per SIMD of __launch_bounds__)
-  int rays;      // pool4: rays a lane walks at the same time (1 or 2)
+  int rays;      // pool4: rays a lane walks at the same time (1; two measured slower and are not built)
+  bool group;    // pool4: one pool and one set of queues per workgroup (VIMG_SCHED_POOL4G) instead of per wave
   bool deep;     // pooled / staged kernel: build whose box loop yields to waiting leaves (tree beyond the LDS node cache)
 };
 
 using RenderKernel = void (*)(const DScene, const RenderArgs, float*, DeviceStats*, unsigned int*);
 using StageKernel = void (*)(const StageKArgs*);
 using Pool4Kernel = void (*)(const Pool4KArgs*);
-Pool4Kernel pick_pool4_kernel(const VimgDeviceScene* s, bool deep, int wps, int rays);
+Pool4Kernel pick_pool4_kernel(const VimgDeviceScene* s, bool deep, int wps, bool group);
 RenderKernel pick_kernel(const VimgDeviceScene* s, bool pooled, int wps, bool deep) {
   if (pooled) {
     if (deep) {
@@ -300,23 +302,23 @@ StageKernel pick_stage_kernel(const VimgDeviceScene* s, bool deep) {
   if (s->textured) return deep ? render_stage_kernel<true, true> : render_stage_kernel<true, false>;
   return deep ? render_stage_kernel<false, true> : render_stage_kernel<false, false>;
 }
-template <int WPS, int NC>
+template <int WPS, bool GRP>
 Pool4Kernel pool4_build(bool tex, bool deep) {
-  if (tex) return deep ? render_pool4_kernel<true, true, WPS, NC> : render_pool4_kernel<true, false, WPS, NC>;
-  return deep ? render_pool4_kernel<false, true, WPS, NC> : render_pool4_kernel<false, false, WPS, NC>;
+  if (tex) return deep ? render_pool4_kernel<true, true, WPS, 1, GRP> : render_pool4_kernel<true, false, WPS, 1, GRP>;
+  return deep ? render_pool4_kernel<false, true, WPS, 1, GRP> : render_pool4_kernel<false, false, WPS, 1, GRP>;
 }
 // (two rays per lane - NC = 2, both stepped in one pass of the box loop - measured slower and is not
 // built: config 2 9.3 against 11.7 Grays/s at 64 spp, 228 B of scratch; the loop runs until the
 // last of 128 rays instead of 64 has reached a leaf, which costs more lanes than the interleaving
 // hides latency)
-Pool4Kernel pick_pool4_kernel(const VimgDeviceScene* s, bool deep, int wps, int rays) {
-  (void)rays;
-  if (wps >= 4) return pool4_build<4, 1>(s->textured, deep);
-  return pool4_build<3, 1>(s->textured, deep);
+Pool4Kernel pick_pool4_kernel(const VimgDeviceScene* s, bool deep, int wps, bool group) {
+  if (group) return pool4_build<3, true>(s->textured, deep);
+  if (wps >= 4) return pool4_build<4, false>(s->textured, deep);
+  return pool4_build<3, false>(s->textured, deep);
 }
 const void* kernel_of(const VimgDeviceScene* s, const LaunchCfg& c) {
   if (c.sched == VIMG_SCHED_STAGE) return reinterpret_cast<const void*>(pick_stage_kernel(s, c.deep));
-  if (c.sched == VIMG_SCHED_POOL4) return reinterpret_cast<const void*>(pick_pool4_kernel(s, c.deep, c.wps, c.rays));
+  if (c.sched == VIMG_SCHED_POOL4) return reinterpret_cast<const void*>(pick_pool4_kernel(s, c.deep, c.wps, c.group));
   return reinterpret_cast<const void*>(pick_kernel(s, c.pooled, c.wps, c.deep));
 }
 
@@ -347,8 +349,11 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   const bool by_policy = (sched == 0);
   if (!for_render) sched = VIMG_SCHED_LANE;   // probes and the heatmap only need the LDS layout
   if (sched == 0) sched = VIMG_SCHED_POOL4;
+  c.group = (sched == VIMG_SCHED_POOL4G);
+  if (c.group) sched = VIMG_SCHED_POOL4;   // the same launch in everything but the pool's layout and the kernel build
   if (s->too_wide && sched != VIMG_SCHED_LANE) sched = VIMG_SCHED_LANE;        // slots pack pixel coordinates in 16 bits
   if (sched == VIMG_SCHED_STAGE && items > (1ull << 26)) sched = VIMG_SCHED_POOL4;   // 32-bit byte offsets of the pixel records
+  if (sched != VIMG_SCHED_POOL4) c.group = false;
   c.sched = sched;
   c.pooled = (sched == VIMG_SCHED_POOL || sched == VIMG_SCHED_POOL4);
   // register budget: the lane-bound kernel wants 3 waves per SIMD on scenes beyond the on-chip
@@ -361,7 +366,7 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   // pool4: three waves per SIMD by policy (config 2: 12.2 Grays/s at three, 11.3 at four; the stand-ins
   // of configs 3 / 4 / 5: 6.6 / 1.56 / 2.62 against 6.1 / 1.15 / 1.52 - a wave's LDS share, i.e. its
   // pool, shrinks faster than the fourth wave pays, most of all under the deep trees' stacks)
-  if (sched == VIMG_SCHED_POOL4) c.wps = (o.waves_per_simd == 4) ? 4 : 3;
+  if (sched == VIMG_SCHED_POOL4) c.wps = (o.waves_per_simd == 4 && !c.group) ? 4 : 3;
   c.rays = 1;
   RenderArgs& a = c.args;
   a.integrator = p->integrator;
@@ -401,6 +406,7 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   // config 4 / 5 stand-ins: never 1.02 / 1.74, 8 lanes 1.19 / 2.10, 16: 1.18 / 2.13, 24: 1.20 / 2.13,
   // 40: 1.15 / 1.93 Grays/s
   a.pool_boxmin = std::min(64u, opt_or(o.pool_boxmin, 16u));
+  a.pool_gbreak = std::min(64u, opt_or(o.pool_gbreak, 32u));
 
   c.deep = (sched != VIMG_SCHED_LANE) && a.lds_nodes < s->d.num_nodes;   // the other build reads every node from LDS
   if (!c.deep && a.stack_lds < a.stack_entries) return make_launch(s, p, sx, sy, for_render, sched_override, true);
@@ -420,33 +426,52 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
     leaf_bytes = a.lds_leaf * 48u;
   }
   if (c.pooled) {
+    // Pixels are the unit of parallelism (one sequential RNG stream per pixel): a launch with few
+    // pixels per wave is fastest with pools of about pixels / 2.4 slots, and with very few the
+    // lane-bound kernel wins - the pooled scheduler's hop latency times the longest pixel's chain of
+    // path vertices is then the whole frame time.  By policy only; what is asked for by name stands.
+    const bool policy_pool4 = sched == VIMG_SCHED_POOL4 && by_policy && !sched_override && o.pool_slots == VIMG_OPT_AUTO;
+    uint64_t want = ~0ull;
+    if (policy_pool4) {
+      if (sx >= 0) return make_launch(s, p, sx, sy, for_render, VIMG_SCHED_LANE);   // trace_pixel: one path
+      const uint64_t waves = uint64_t(s->num_cus) * 3u * 4u;   // three workgroups per CU (checked against the runtime below)
+      want = items * 10u / (waves * 24u);
+      if (want < 40u) return make_launch(s, p, sx, sy, for_render, VIMG_SCHED_LANE);
+    }
     // the pool takes what is left of this workgroup's share of the CU's 160 KiB
     const uint32_t share = (160u * 1024u) / uint32_t(c.wps) - 1024u;
-    const uint32_t slot_bytes = (sched == VIMG_SCHED_POOL4) ? P4_LDS_BYTES : POOL_LDS_BYTES;
-    const uint32_t per_slot = slot_bytes * 4u;   // LDS bytes per slot, all four waves
     if (sched == VIMG_SCHED_POOL4) c.lds_bytes += 4u * uint32_t(sizeof(Pool4Wave) + sizeof(Pool4Diag));
-    uint32_t slots = share > c.lds_bytes + leaf_bytes + 64u ? (share - c.lds_bytes - leaf_bytes - 64u) / per_slot : 0;
-    slots = std::min(slots, 256u);
+    auto slots_for = [&](uint32_t slot_bytes, uint32_t extra) {
+      const uint32_t used = c.lds_bytes + extra + leaf_bytes + 64u;
+      return std::min(share > used ? (share - used) / (slot_bytes * 4u) : 0u, 256u);
+    };
+    uint32_t slots = slots_for((sched == VIMG_SCHED_POOL4) ? P4_LDS_BYTES : POOL_LDS_BYTES, 0);
+    // Which pool4 build (by policy).  One pool per WAVE when the pools are large (trees in LDS on a
+    // full frame: config 2 12.3 against 11.9 Grays/s - the group's lock costs more than its fuller
+    // batches earn).  One pool per WORKGROUP when they are small: trees in global memory, whose
+    // stacks take half the LDS (stand-ins of configs 4 / 5, 32 spp: 1.72 -> 2.07, 2.81 -> 3.22
+    // Grays/s), and frames with few pixels per wave (half of config 2: 238 -> 209 ms; a quarter:
+    // lane-bound 205 -> 180 ms with 64 slots; an eighth stays with the lane-bound kernel, 139 ms).
+    if (policy_pool4) c.group = c.wps == 3 && (c.deep || want < slots);
+    if (c.group) {
+      c.lds_bytes += pool4g_group_bytes(0);   // group record, batch rows
+      slots = slots_for(P4G_LDS_BYTES, 0);
+    }
+    const uint32_t slot_bytes = c.group ? P4G_LDS_BYTES : (sched == VIMG_SCHED_POOL4) ? P4_LDS_BYTES : POOL_LDS_BYTES;
     if (o.pool_slots != VIMG_OPT_AUTO) slots = std::min(slots, uint32_t(std::max(0, o.pool_slots)));
     a.pool_slots = std::max(slots, 8u);
     if (sched == VIMG_SCHED_POOL4) {
-      // Pixels are the unit of parallelism (one sequential RNG stream per pixel): a launch with few
-      // pixels per wave is fastest with pools of about pixels / 2.4 slots (half of config 2, 720 K
-      // pixels on 3072 waves: 186 slots 310 ms, 128: 241, 96: 239, 80: 259), and below 64 slots per
-      // wave the lane-bound kernel wins (a quarter of config 2: pool4 237 ms, lane-bound 205; an
-      // eighth: 222 / 137) - the pooled scheduler's hop latency times the longest pixel's chain of
-      // path vertices is then the whole frame time.  By policy only; a pool size asked for by name stands.
-      if (by_policy && !sched_override && o.pool_slots == VIMG_OPT_AUTO) {
-        if (sx >= 0) return make_launch(s, p, sx, sy, for_render, VIMG_SCHED_LANE);   // trace_pixel: one path
-        int per_cu_guess = 3;   // workgroups per CU of this build (checked against the runtime below)
-        const uint64_t waves = uint64_t(s->num_cus) * uint32_t(per_cu_guess) * 4u;
-        const uint64_t want = items * 10u / (waves * 24u);
-        if (want < 64u) return make_launch(s, p, sx, sy, for_render, VIMG_SCHED_LANE);
-        a.pool_slots = static_cast<uint32_t>(std::min<uint64_t>(a.pool_slots, want));
-      }
-      a.pool_slots &= ~1u;   // even: every wave's cold region starts on a 64-byte line
+      if (policy_pool4) a.pool_slots = static_cast<uint32_t>(std::min<uint64_t>(a.pool_slots, std::max<uint64_t>(want, 64u)));
+      a.pool_slots &= ~1u;   // even: every wave's cold region starts on a 64-byte line (and a group's tables on 16 bytes)
     }
-    c.lds_bytes += 4u * ((slot_bytes * a.pool_slots + 15u) & ~15u) + leaf_bytes;
+    c.lds_bytes += (c.group ? slot_bytes * 4u * a.pool_slots : 4u * ((slot_bytes * a.pool_slots + 15u) & ~15u)) + leaf_bytes;
+    // vertex queues and thresholds of the group build: one queue per material class again (the
+    // group's queues fill), 32 idle lanes before a partial batch, a full batch taken by a wave with
+    // at most 32 rays in its lanes
+    if (c.group) {
+      a.pool_classes = std::min(3u, std::max(1u, opt_or(o.pool_classes, 3u)));
+      a.pool_gbreak = std::min(64u, opt_or(o.pool_gbreak, 32u));
+    }
   }
   StageArgs& g = c.stage;
   if (sched == VIMG_SCHED_STAGE) {
@@ -618,7 +643,7 @@ int enqueue_render(VimgDeviceScene* s, const VimgRenderParams* p, float* d_out, 
     Pool4KArgs* blk = static_cast<Pool4KArgs*>(s->d_stage_kargs);
     hipLaunchKernelGGL(pool4_args_kernel, dim3(1), dim3(64), 0, st, Pool4KArgs{s->d, c.args, d_out, stats, s->d_counter}, blk);
     if (ev0) HIP_TRY(hipEventRecord(ev0, st));
-    hipLaunchKernelGGL(pick_pool4_kernel(s, c.deep, c.wps, c.rays), dim3(c.grid), dim3(256), c.lds_bytes, st,
+    hipLaunchKernelGGL(pick_pool4_kernel(s, c.deep, c.wps, c.group), dim3(c.grid), dim3(256), c.lds_bytes, st,
                        static_cast<const Pool4KArgs*>(blk));
   } else
     hipLaunchKernelGGL(pick_kernel(s, c.pooled, c.wps, c.deep), dim3(c.grid), dim3(256), c.lds_bytes, st, s->d, c.args,
@@ -990,7 +1015,7 @@ int vimg_hip_scene_upload_opts(const VimgScene* sc, const VimgHipOptions* opts, 
     s->opt.struct_size = sizeof(VimgHipOptions);
   }
   options_from_env(&s->opt);
-  if (s->opt.scheduler != VIMG_OPT_AUTO && (s->opt.scheduler < VIMG_SCHED_LANE || s->opt.scheduler > VIMG_SCHED_POOL4))
+  if (s->opt.scheduler != VIMG_OPT_AUTO && (s->opt.scheduler < VIMG_SCHED_LANE || s->opt.scheduler > VIMG_SCHED_POOL4G))
     return bail(fail(VIMG_E_INVALID, "options: unknown scheduler"));
   s->too_wide = (cam.res_x > 65535 || cam.res_y > 65535);   // slots pack pixel coordinates in 16 bits
   hipDeviceProp_t prop{};
@@ -1034,6 +1059,9 @@ const char* vimg_hip_launch_kernel(const VimgDeviceScene* s, const VimgRenderPar
   static const char* pool4_names[2][2] = {{"render_pool4_kernel<false>", "render_pool4_kernel<false,deep>"},
                                           {"render_pool4_kernel<true>", "render_pool4_kernel<true,deep>"}};   // (+ waves per SIMD, rays per lane)
   if (c.sched == VIMG_SCHED_STAGE) return stage_names[s->textured ? 1 : 0][c.deep ? 1 : 0];
+  static const char* pool4g_names[2][2] = {{"render_pool4_kernel<false,group>", "render_pool4_kernel<false,deep,group>"},
+                                           {"render_pool4_kernel<true,group>", "render_pool4_kernel<true,deep,group>"}};
+  if (c.sched == VIMG_SCHED_POOL4 && c.group) return pool4g_names[s->textured ? 1 : 0][c.deep ? 1 : 0];
   if (c.sched == VIMG_SCHED_POOL4) return pool4_names[s->textured ? 1 : 0][c.deep ? 1 : 0];
   if (c.deep) return deep_names[s->textured ? 1 : 0][c.wps >= 3 ? 1 : 0];
   return names[c.pooled ? 1 : 0][s->textured ? 1 : 0][c.wps >= 3 ? 1 : 0];
