@@ -436,7 +436,10 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
       if (sx >= 0) return make_launch(s, p, sx, sy, for_render, VIMG_SCHED_LANE);   // trace_pixel: one path
       const uint64_t waves = uint64_t(s->num_cus) * 3u * 4u;   // three workgroups per CU (checked against the runtime below)
       want = items * 10u / (waves * 24u);
-      if (want < 40u) return make_launch(s, p, sx, sy, for_render, VIMG_SCHED_LANE);
+      // (trees in global memory never go there: the lane-bound kernel pays a memory round trip per
+      // phase of its machine - quarter / eighth of the config-4 stand-in, 128 spp: 261 / 243 ms against
+      // 134 / 112 ms with group pools of 32 slots per wave)
+      if (want < 40u && !c.deep) return make_launch(s, p, sx, sy, for_render, VIMG_SCHED_LANE);
     }
     // the pool takes what is left of this workgroup's share of the CU's 160 KiB
     const uint32_t share = (160u * 1024u) / uint32_t(c.wps) - 1024u;
@@ -461,7 +464,8 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
     if (o.pool_slots != VIMG_OPT_AUTO) slots = std::min(slots, uint32_t(std::max(0, o.pool_slots)));
     a.pool_slots = std::max(slots, 8u);
     if (sched == VIMG_SCHED_POOL4) {
-      if (policy_pool4) a.pool_slots = static_cast<uint32_t>(std::min<uint64_t>(a.pool_slots, std::max<uint64_t>(want, 64u)));
+      if (policy_pool4)
+        a.pool_slots = static_cast<uint32_t>(std::min<uint64_t>(a.pool_slots, std::max<uint64_t>(want, c.deep ? 32u : 64u)));
       a.pool_slots &= ~1u;   // even: every wave's cold region starts on a 64-byte line (and a group's tables on 16 bytes)
     }
     c.lds_bytes += (c.group ? slot_bytes * 4u * a.pool_slots : 4u * ((slot_bytes * a.pool_slots + 15u) & ~15u)) + leaf_bytes;
