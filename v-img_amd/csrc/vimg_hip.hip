@@ -312,7 +312,7 @@ Pool4Kernel pool4_build(bool tex, bool deep) {
 // last of 128 rays instead of 64 has reached a leaf, which costs more lanes than the interleaving
 // hides latency)
 Pool4Kernel pick_pool4_kernel(const VimgDeviceScene* s, bool deep, int wps, bool group) {
-  if (group) return pool4_build<3, true>(s->textured, deep);
+  if (group) return wps >= 4 ? pool4_build<4, true>(s->textured, deep) : pool4_build<3, true>(s->textured, deep);
   if (wps >= 4) return pool4_build<4, false>(s->textured, deep);
   return pool4_build<3, false>(s->textured, deep);
 }
@@ -366,7 +366,7 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   // pool4: three waves per SIMD by policy (config 2: 12.2 Grays/s at three, 11.3 at four; the stand-ins
   // of configs 3 / 4 / 5: 6.6 / 1.56 / 2.62 against 6.1 / 1.15 / 1.52 - a wave's LDS share, i.e. its
   // pool, shrinks faster than the fourth wave pays, most of all under the deep trees' stacks)
-  if (sched == VIMG_SCHED_POOL4) c.wps = (o.waves_per_simd == 4 && !c.group) ? 4 : 3;
+  if (sched == VIMG_SCHED_POOL4) c.wps = (o.waves_per_simd == 4) ? 4 : 3;
   c.rays = 1;
   RenderArgs& a = c.args;
   a.integrator = p->integrator;
@@ -440,6 +440,15 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
       // phase of its machine - quarter / eighth of the config-4 stand-in, 128 spp: 261 / 243 ms against
       // 134 / 112 ms with group pools of 32 slots per wave)
       if (want < 40u && !c.deep) return make_launch(s, p, sx, sy, for_render, VIMG_SCHED_LANE);
+      // A full frame on a tree in LDS: FOUR waves per SIMD with group pools (config 2, 512 spp: 13.4
+      // against 12.7 Grays/s with three waves and per-wave pools - the fourth wave's issue slots pay
+      // now that its smaller LDS share no longer thins the batches; config 3: 7.63 against 7.47).
+      // Shards keep three (half of config 2: 209 against 226 ms), and so do trees in global memory
+      // (their stacks leave a four-wave workgroup no LDS for slots: 1.34 against 2.09 Grays/s).
+      if (!c.deep && o.waves_per_simd == VIMG_OPT_AUTO && want >= 160u) {
+        c.wps = 4;
+        want = want * 3u / 4u;   // per wave of the larger grid
+      }
     }
     // the pool takes what is left of this workgroup's share of the CU's 160 KiB
     const uint32_t share = (160u * 1024u) / uint32_t(c.wps) - 1024u;
@@ -449,13 +458,14 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
       return std::min(share > used ? (share - used) / (slot_bytes * 4u) : 0u, 256u);
     };
     uint32_t slots = slots_for((sched == VIMG_SCHED_POOL4) ? P4_LDS_BYTES : POOL_LDS_BYTES, 0);
-    // Which pool4 build (by policy).  One pool per WAVE when the pools are large (trees in LDS on a
-    // full frame: config 2 12.3 against 11.9 Grays/s - the group's lock costs more than its fuller
-    // batches earn).  One pool per WORKGROUP when they are small: trees in global memory, whose
+    // Which pool4 build (by policy).  One pool per WAVE only when three waves per SIMD are asked for
+    // on a full frame of a tree in LDS (config 2 12.3 against 11.9 Grays/s - there the group's lock
+    // costs more than its fuller batches earn).  One pool per WORKGROUP otherwise: at four waves per
+    // SIMD (above), and wherever pools are small - trees in global memory, whose
     // stacks take half the LDS (stand-ins of configs 4 / 5, 32 spp: 1.72 -> 2.07, 2.81 -> 3.22
     // Grays/s), and frames with few pixels per wave (half of config 2: 238 -> 209 ms; a quarter:
     // lane-bound 205 -> 180 ms with 64 slots; an eighth stays with the lane-bound kernel, 139 ms).
-    if (policy_pool4) c.group = c.wps == 3 && (c.deep || want < slots);
+    if (policy_pool4) c.group = c.wps == 4 || c.deep || want < slots;
     if (c.group) {
       c.lds_bytes += pool4g_group_bytes(0);   // group record, batch rows
       slots = slots_for(P4G_LDS_BYTES, 0);
