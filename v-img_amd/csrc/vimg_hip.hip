@@ -531,7 +531,10 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
     // 3600x1600, 14 generations: 1 segment 7.9, 4: 7.7) - about 56 segments per generation count,
     // at most 16, of at least 4 samples; frames of 10 generations and more keep their pixels whole
     const double gens = double(items) / double(in_flight);
-    uint32_t k = gens >= 10.0 ? 1u : uint32_t(std::min(16.0, std::max(1.0, std::floor(56.0 / gens + 0.5))));
+    // (group pools at four waves, config 2 at 512 spp, 2.75 generations: 8 segments 322.5 ms, 16: 315.3,
+    // 32: 312.9, 64: 311.4 - the pooled kernels before it were flat from 16 on)
+    const bool more = c.group && c.wps == 4;
+    uint32_t k = gens >= 10.0 ? 1u : uint32_t(std::min(more ? 64.0 : 16.0, std::max(1.0, std::floor((more ? 176.0 : 56.0) / gens + 0.5))));
     k = std::min<uint32_t>(k, std::max<uint32_t>(p->samples / 4u, 1u));
     if (items * 2u < in_flight * 3u) k = 1u;
     if (o.pool_segments != VIMG_OPT_AUTO) k = uint32_t(std::max(1, o.pool_segments));
