@@ -37,11 +37,11 @@ int vimg_hip_init(int device_ordinal);
 int vimg_hip_device_count(void);
 
 /* How a scene's frames are scheduled on the GPU.  Every field: VIMG_OPT_AUTO (-1) = the library's
- * policy (stated per field); the three schedulers execute the same per-path arithmetic and give
+ * policy (stated per field); the schedulers execute the same per-path arithmetic and give
  * the same bits.  The reference has no counterpart (its scheduler is the tile loop of
  * include/integrators.h:57-101); these are the knobs of OUR replacement of that loop, at the
  * boundary instead of in the environment.  (For tools/ only, VIMG_HIP_* environment variables
- * still override single fields at upload: scheduler VIMG_HIP_SCHED=lane|pool|stage, the others
+ * still override single fields at upload: scheduler VIMG_HIP_SCHED=lane|pool|stage|pool4|pool4g, the others
  * as named in vimg_hip.hip:options_from_env.) */
 #define VIMG_OPT_AUTO (-1)
 enum {
@@ -53,14 +53,14 @@ enum {
 };
 typedef struct VimgHipOptions {
   uint32_t struct_size;       /* sizeof(VimgHipOptions): lets the library accept older callers */
-  int32_t scheduler;          /* AUTO: POOL4; LANE for launches with fewer pixels than 1.5 x the pooled slots in flight */
-  int32_t waves_per_simd;     /* register budget: LANE / POOL 2 or 3 (AUTO: LANE 3 for scenes > 32 MiB else 2; POOL 2), POOL4 3 or 4 (AUTO 3) */
+  int32_t scheduler;          /* AUTO (vimg_hip.hip:make_launch): POOL4G; LANE for launches of small scenes with fewer than ~96 pixels per wave and for trace_pixel */
+  int32_t waves_per_simd;     /* register budget: LANE / POOL 2 or 3 (AUTO: LANE 3 for scenes > 32 MiB else 2; POOL 2), POOL4 / POOL4G 3 or 4 (AUTO: 4 for full frames on trees that fit in LDS, else 3) */
   int32_t lds_budget_kb;      /* LDS per workgroup for BVH top + stacks.  AUTO: 40 (LANE), stacks + 4.5 (POOL / STAGE) */
   int32_t pool_slots;         /* POOL: path slots per wave.  AUTO: what the CU's LDS holds (<= 256) */
-  int32_t pool_segments;      /* POOL: segments a pixel's samples are cut into.  AUTO: ~56 / pool generations, <= 16 */
+  int32_t pool_segments;      /* POOL: segments a pixel's samples are cut into.  AUTO: ~56 / pool generations, <= 16 (POOL4G at four waves: ~176 / generations, <= 64) */
   int32_t pool_refill;        /* POOL / STAGE walk: finished rays that trigger a refill pass.  AUTO 16 */
   int32_t pool_vbatch;        /* POOL: queued slots of one class that start a vertex batch.  AUTO 64 */
-  int32_t pool_classes;       /* POOL: vertex queues by material, 1..3.  AUTO 3; POOL4 on trees beyond LDS: 1 */
+  int32_t pool_classes;       /* POOL: vertex queues by material, 1..3.  AUTO 3; per-wave POOL4 on trees beyond LDS: 1 */
   int32_t pool_starve;        /* POOL: idle walk lanes that force a partial vertex batch.  AUTO 24; POOL4 on trees beyond LDS: 32 */
   int32_t pool_boxmin;        /* POOL / STAGE, deep trees: leave the box loop below this many descending lanes.  AUTO 16 */
   int32_t lds_leaf;           /* POOL / STAGE: 0 = never copy the leaf records to LDS.  AUTO: when they fit 4 KiB */

@@ -1,20 +1,22 @@
-// Pooled scheduler, second build: the same per-wave pools of path slots, the same wave-private
-// queues, the same segment hand-over as render_pool_kernel (see its header comment) - but the
-// VERTEX stage is a real (non-inlined) function per batch class, and the kernel is built for FOUR
-// waves per SIMD.
+// Pooled scheduler, second build: the same pools of path slots, the same queues, the same segment
+// hand-over as render_pool_kernel (see its header comment) - but the VERTEX stage is a real
+// (non-inlined) function per batch class, the kernel is built for three and for four waves per SIMD,
+// and (GRP builds) the four waves of a workgroup share one pool and one set of queues.
 //
-// Why (profiles/r1_flat, ISA of render_pool_kernel): with everything inlined the register
+// Why calls (profiles/r1_flat, ISA of render_pool_kernel): with everything inlined the register
 // allocator keeps the walk's persistent lane state, the batch's slot state and the shading
 // temporaries alive together - 255 VGPRs + 336 B of scratch at two waves per SIMD, and a SIMD with
 // two waves issues a vector instruction at best every other slot each (38 % issue measured).
 // Compiled on their own the vertex stages need 74 (Lambertian) to 126 (Principled) registers.
-// As calls they get a fresh register file: the walk's lane state sits in callee-saved registers
-// (about 40 scratch stores + loads per BATCH, i.e. per ~64 vertices), the wave-uniform scheduler
-// state (queue heads and counts) travels through a 64-byte record in LDS, scene and launch
-// parameters are read from one block in device memory through the constant address space (a
-// callee has no kernel-argument pointer).  128 VGPRs, no scratch in the loops, 16 waves per CU.
-// The pools shrink with the LDS share of a wave (the RNG record moves to the cold records in
-// global memory to win some of it back).  Same arithmetic, same order: bit-identical.
+// As calls they get a fresh register file: the walk's lane state sits in callee-saved registers,
+// the wave-uniform scheduler state (queue heads and counts) travels through a 64-byte record in
+// LDS, scene and launch parameters are read from one block in device memory through the constant
+// address space (a callee has no kernel-argument pointer).  The pools shrink with the LDS share of
+// a wave (the RNG record moves to the cold records in global memory to win some of it back).
+//
+// Why group pools: the rate of this scheduler is passes x lanes per pass in
+// the walk and batches x slots per batch in the vertex stage, and both fills hang on the slots a
+// wave can draw from.  Same arithmetic, same order in every build: bit-identical.
 #pragma once
 #include <type_traits>
 
