@@ -961,6 +961,60 @@ def test_leaves_of_more_than_127_primitives(leaf_cap):
     assert same > 0.97
 
 
+def test_a_tree_deeper_than_the_lds_stack():
+    """The stack bound of the boundary is 94 levels; the pooled kernels keep at most the first 32
+    entries of a lane's stack in LDS and the rest in global memory (by policy: a tree that deep would
+    otherwise leave its workgroup no LDS for path slots).  A caller's builder hands over a
+    "caterpillar" - every internal node has one leaf child and the rest of the primitives as the
+    other - 49 levels deep; the image and the event counts must be the oracle's on the SAME tree, on
+    the lane-bound kernel and on both pooled builds with their default stack split."""
+    import ctypes as C
+    from vimg_amd import abi
+    BUILDER = C.CFUNCTYPE(C.c_int, C.c_uint32, abi.Pf32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                          C.c_void_p, abi.Pf32, C.POINTER(C.c_uint32))
+
+    def caterpillar(n, bounds6, num_nodes, max_depth, nodes_p, bb_p, obj_p):
+        b = np.ctypeslib.as_array(bounds6, (n, 6)).copy()
+        nodes = np.ctypeslib.as_array(C.cast(nodes_p, C.POINTER(C.c_uint32)), (2 * n - 1, 2))
+        bb = np.ctypeslib.as_array(bb_p, (2 * (2 * n - 1) + 3, 3))
+        obj = np.ctypeslib.as_array(obj_p, (n,))
+        order = np.argsort((b[:, 0] + b[:, 3]) + 0.37 * (b[:, 2] + b[:, 5]), kind="stable")
+        obj[:] = order
+        bb[0], bb[2] = b[:, :3].min(0), b[:, 3:].max(0)
+        node, nxt = 0, 1
+        for i in range(n - 1):              # node: leaf {order[i]} | everything behind it
+            first = nxt
+            nxt += 2
+            nodes[node] = (first, 0)
+            rest = order[i + 1:]
+            bb[2 * first + 2], bb[2 * first + 4] = b[order[i], :3], b[order[i], 3:]
+            bb[2 * first + 3], bb[2 * first + 5] = b[rest, :3].min(0), b[rest, 3:].max(0)
+            nodes[first] = (i, 1)
+            node = first + 1
+        nodes[node] = (n - 1, 1)
+        num_nodes[0], max_depth[0] = nxt, n
+        return 0
+
+    cb = BUILDER(caterpillar)
+    s = scenes.big_mesh_scene(res=(64, 48), n=4)        # 2 * 4 * 4 = 32 triangles + walls and a light
+    s.build_bvh_with(C.cast(cb, C.c_void_p))
+    bvh = s.view.contents.bvh
+    assert 34 < bvh.max_depth <= 92, bvh.max_depth
+    p = s.default_params(samples=6)
+    cpu, cst, _ = O.render(s, p)
+    lane, lst = _dev_opts(s, scheduler="lane").render_to_host(p)
+    _compare_images(lane, cpu, f"caterpillar tree of depth {bvh.max_depth}")
+    for k in ("closest_rays", "shadow_rays", "internal_visits", "leaf_visits", "prim_tests"):
+        a, b = getattr(lst, k), getattr(cst, k)
+        assert abs(a - b) <= max(64, 1e-3 * b), (k, a, b)
+    for sched in ("pool4", "pool4g"):
+        d = _dev_opts(s, scheduler=sched)
+        assert "deep" in d.kernel, d.kernel
+        gpu, gst = d.render_to_host(p)
+        assert np.array_equal(gpu.view(np.uint32), lane.view(np.uint32)), (sched, d.kernel)
+        assert gst.as_dict() == lst.as_dict(), sched
+
+
 def test_bench_self_launches_two_ranks():
     """`python bench.py --gpus 2` with no rendezvous in the environment must start the ranks itself
     (fresh child processes; the driver invokes it exactly like this) and relay one JSON line.
