@@ -961,6 +961,27 @@ def test_leaves_of_more_than_127_primitives(leaf_cap):
     assert same > 0.97
 
 
+def test_launch_policy_picks_the_builds_design_md_names():
+    """vimg_hip.hip:make_launch: a full frame on a tree in LDS gets the group build
+    (four waves per SIMD), thin shards of it the group build too and very thin ones the lane-bound
+    kernel; a tree in global memory gets the group build at every shard width; trace_pixel always the
+    lane-bound kernel.  (What each of them renders is the business of the parity tests above.)"""
+    s = scenes.json_scene("disney_spheres.json")                       # 1800 x 800
+    d = _dev(s)
+    assert d.kernel_for(s.default_params(samples=4)) == "render_pool4_kernel<false,group>"
+    assert d.kernel_for(s.default_params(samples=4, tile_world=2)) == "render_pool4_kernel<false,group>"
+    assert d.kernel_for(s.default_params(samples=4, tile_world=4)) == "render_pool4_kernel<false,group>"
+    assert d.kernel_for(s.default_params(samples=4, tile_world=8)).startswith("render_kernel<false")
+    small = _dev(scenes.json_scene("disney_spheres.json", res=(136, 72)))
+    assert small.kernel_for(s.default_params(samples=4)).startswith("render_kernel<false")
+    deep = scenes.config4_scene(n_lat=48, env=(128, 64))               # 1366 x 768, tree beyond LDS
+    dd = _dev(deep)
+    for tw in (1, 2, 4, 8):
+        assert dd.kernel_for(deep.default_params(samples=4, tile_world=tw)) == "render_pool4_kernel<true,deep,group>", tw
+    by_name = _dev_opts(s, scheduler="pool4")
+    assert by_name.kernel_for(s.default_params(samples=4)) == "render_pool4_kernel<false>"
+
+
 def test_a_tree_deeper_than_the_lds_stack():
     """The stack bound of the boundary is 94 levels; the pooled kernels keep at most the first 32
     entries of a lane's stack in LDS and the rest in global memory (by policy: a tree that deep would
