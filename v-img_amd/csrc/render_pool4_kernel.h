@@ -861,6 +861,7 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
 #ifdef VIMG_WALK_DIAG   // measurement build only: where a walk round's cycles go (wave-uniform accumulators)
   unsigned long long wd_fill = 0, wd_box = 0, wd_leaf = 0, wd_ret = 0, wd_t = 0;
   unsigned long long wd_nbox = 0, wd_boxlanes = 0, wd_nleaf = 0, wd_leaflanes = 0, wd_primtrips = 0;
+  unsigned long long wd_lockwait = 0, wd_lockhold = 0, wd_nlock = 0;   // group build, retire: until the lock is held / until it is released
 #define WD_MARK() (wd_t = __builtin_readcyclecounter())
 #define WD_ADD(acc) do { const unsigned long long n_ = __builtin_readcyclecounter(); acc += n_ - wd_t; wd_t = n_; } while (0)
 #else
@@ -1265,9 +1266,15 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
                                    m2 = __ballot(done_item && cls == 2),
                                    m3 = __ballot(done_item && cls == 3);
           const bool any_done = (m0 | m1 | m2 | m3) != 0ull;
+#ifdef VIMG_WALK_DIAG
+          const unsigned long long wd_l0 = __builtin_readcyclecounter();
+#endif
           if constexpr (GRP) {
             if (any_done) {
               grp_lock(G, work_counter + 1);
+#ifdef VIMG_WALK_DIAG
+              wd_lockwait += __builtin_readcyclecounter() - wd_l0, wd_nlock += 1;
+#endif
               qv_head0 = uni(G->qv_head[0]), qv_head1 = uni(G->qv_head[1]), qv_head2 = uni(G->qv_head[2]), qv_head3 = uni(G->qv_head[3]);
               qv_count0 = uni(G->qv_count[0]), qv_count1 = uni(G->qv_count[1]), qv_count2 = uni(G->qv_count[2]), qv_count3 = uni(G->qv_count[3]);
             } else {
@@ -1308,6 +1315,9 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
                 if (lane == 0) G->qw_head = qw_head, G->qw_count = qw_count;
               }
               grp_unlock(G);
+#ifdef VIMG_WALK_DIAG
+              wd_lockhold += __builtin_readcyclecounter() - wd_l0;
+#endif
             }
           }
         }
@@ -1358,8 +1368,9 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
         for (int k = 0; k < 4; ++k) atomicAdd(&stats->prof[6 + k], dg->nbatch[k]), atomicAdd(&stats->prof[11 + k], dg->nslots[k]);
         atomicAdd(&stats->prof[10], 1ull);
 #ifdef VIMG_WALK_DIAG
-        const unsigned long long wd[10] = {wd_fill, wd_box, wd_leaf, wd_ret, wd_nbox, wd_boxlanes, wd_nleaf, wd_leaflanes, wd_primtrips, 0};
-        for (int k = 0; k < 9; ++k) atomicAdd(&stats->prof[16 + k], wd[k]);
+        const unsigned long long wd[12] = {wd_fill, wd_box, wd_leaf, wd_ret, wd_nbox, wd_boxlanes, wd_nleaf, wd_leaflanes, wd_primtrips,
+                                           wd_lockwait, wd_lockhold, wd_nlock};
+        for (int k = 0; k < 12; ++k) atomicAdd(&stats->prof[16 + k], wd[k]);
 #endif
       }
     }

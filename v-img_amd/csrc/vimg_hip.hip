@@ -721,9 +721,10 @@ int fetch_stats(VimgDeviceScene* s, const VimgRenderParams* p, VimgRenderStats* 
                    ds.prof[k], 100.0 * double(ds.prof[k]) / double(total ? total : 1), k < 5 ? ds.prof[6 + k] : 0ull,
                    (k < 5 && ds.prof[6 + k]) ? double(ds.prof[11 + k]) / double(ds.prof[6 + k]) : 0.0);
 #ifdef VIMG_WALK_DIAG
-    static const char* wd_names[9] = {"walk: refill+setup cyc", "walk: box loop cyc", "walk: leaf rounds cyc", "walk: retire cyc",
-                                      "box trips", "box lanes", "leaf rounds", "leaf lanes", "leaf prim trips"};
-    for (int k = 0; k < 9; ++k) std::fprintf(stderr, "[vimg walk] %-24s %14llu\n", wd_names[k], ds.prof[16 + k]);
+    static const char* wd_names[12] = {"walk: refill+setup cyc", "walk: box loop cyc", "walk: leaf rounds cyc", "walk: retire cyc",
+                                       "box trips", "box lanes", "leaf rounds", "leaf lanes", "leaf prim trips",
+                                       "retire: cyc to get lock", "retire: cyc to unlock", "retire: lock takes"};
+    for (int k = 0; k < 12; ++k) std::fprintf(stderr, "[vimg walk] %-24s %14llu\n", wd_names[k], ds.prof[16 + k]);
 #endif
   }
 #endif
