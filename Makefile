@@ -22,7 +22,7 @@ ORAFLAGS  := -std=c++20 -O3 -march=x86-64-v3 -fPIC -shared -ffp-contract=off -pt
 HIPFLAGS  := --offload-arch=$(ARCH) -std=c++20 -O3 -fPIC -shared -ffp-contract=off -fno-slp-vectorize \
              -fno-fast-math -Iinclude -Wall -Wno-unused-function
 
-all: host hip oracle oracle-avx2 cli
+all: host hip dev oracle oracle-avx2 cli
 host: $(LIBDIR)/libvimg_host.so
 hip: $(LIBDIR)/libvimg_hip.so
 oracle: oracle/liboracle.so
@@ -32,9 +32,37 @@ $(LIBDIR)/libvimg_host.so: $(HOSTSRC) $(HOSTHDR) Makefile
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(HOSTFLAGS) $(HOSTSRC) -o $@
 
-$(LIBDIR)/libvimg_hip.so: $(HIPSRC) $(HIPHDR) Makefile
+# one object per translation unit (make -j compiles them side by side): the ABI unit, one unit per
+# render kernel family, the BVH builders
+HIPCFLAGS := $(filter-out -shared,$(HIPFLAGS)) -c
+OBJDIR    := build/hip
+HIPOBJ    := $(patsubst v-img_amd/csrc/%.hip,$(OBJDIR)/%.o,$(HIPSRC))
+$(OBJDIR)/%.o: v-img_amd/csrc/%.hip $(HIPHDR) Makefile
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPCFLAGS) $< -o $@
+# render_cu_kernel is ONE persistent loop around every stage: MachineLICM hoists the constants of all
+# of them (the f64 polynomial coefficients of acos / atan2 / pow ...) in front of the loop, where they
+# no longer fit the register file: 533 spilled registers and 700 bytes of scratch per lane with the
+# pass, 80 / 72 without (tools/kres.sh)
+$(OBJDIR)/k_cu.o: HIPCFLAGS += -mllvm -disable-machine-licm
+$(LIBDIR)/libvimg_hip.so: $(HIPOBJ)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) $(HIPSRC) -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(HIPOBJ) -o $@
+
+# development build: the product's kernels plus the two retired schedulers (round 1's pooled kernel,
+# the staged kernel) the GPU tests cross-check against; selected with VIMG_HIP_LIB
+DEVOBJDIR := build/hip_dev
+DEVOBJ    := $(patsubst v-img_amd/csrc/%.hip,$(DEVOBJDIR)/%.o,$(HIPSRC))
+$(DEVOBJDIR)/k_dev.o: v-img_amd/csrc/k_dev.hip $(HIPHDR) Makefile
+	@mkdir -p $(DEVOBJDIR)
+	$(HIPCC) $(HIPCFLAGS) -DVIMG_DEV_SCHEDULERS=1 $< -o $@
+$(DEVOBJDIR)/%.o: $(OBJDIR)/%.o
+	@mkdir -p $(DEVOBJDIR)
+	cp $< $@
+dev: v-img_amd/lib/dev/libvimg_hip.so
+v-img_amd/lib/dev/libvimg_hip.so: $(DEVOBJ)
+	@mkdir -p v-img_amd/lib/dev
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(DEVOBJ) -o $@
 
 # measurement build: stage timers (s_memtime) inside render_pool_kernel; never the product library,
 # selected with VIMG_HIP_LIB by tools/stage_profile.py
@@ -73,6 +101,6 @@ oracle/liboracle_avx2.so: $(ORASRC) $(ORAHDR) Makefile
 	$(CXX) -std=c++20 -O3 -march=x86-64-v3 -fPIC -shared -pthread -Wall -Iinclude -DORACLE_AVX2_TIMING=1 $(ORASRC) -o $@
 
 clean:
-	rm -f $(LIBDIR)/*.so oracle/*.so
+	rm -rf $(LIBDIR)/*.so $(LIBDIR)/dev oracle/*.so build/hip build/hip_dev
 
-.PHONY: all host hip oracle oracle-avx2 cli clean prof diag
+.PHONY: all host hip dev oracle oracle-avx2 cli clean prof diag

@@ -49,7 +49,8 @@ enum {
   VIMG_SCHED_POOL = 2,   /* render_pool_kernel: ~240 path slots per wave in LDS, walk + vertex stages in one wave */
   VIMG_SCHED_STAGE = 3,  /* render_stage_kernel: path state in HBM slots, stages coupled by global queues, 4 waves/SIMD */
   VIMG_SCHED_POOL4 = 4,  /* render_pool4_kernel: the pooled scheduler with the vertex stage as calls */
-  VIMG_SCHED_POOL4G = 5  /* the same with ONE pool and one set of queues per workgroup (four waves share them under a lock in LDS) */
+  VIMG_SCHED_POOL4G = 5, /* the same with ONE pool and one set of queues per workgroup (four waves share them under a lock in LDS) */
+  VIMG_SCHED_CU = 6      /* render_cu_kernel: one pool per compute unit, walking and shading waves, lock-free rings in LDS, both rays of a vertex walked at once */
 };
 typedef struct VimgHipOptions {
   uint32_t struct_size;       /* sizeof(VimgHipOptions): lets the library accept older callers */
@@ -71,6 +72,11 @@ typedef struct VimgHipOptions {
   int32_t pool4_rays;         /* reserved (two rays per lane in the walk measured slower; 1 is what runs) */
   int32_t lds_stack;          /* POOL4, trees beyond LDS: entries of a lane's traversal stack kept in LDS, the rest in global memory.  AUTO 32 */
   int32_t pool_gbreak;        /* POOL4G: a wave leaves the walk for a full vertex batch only with this many rays or fewer in its lanes.  AUTO 32 */
+  int32_t cu_waves;           /* CU: waves per workgroup, 8 or 16 (one 16-wave workgroup is a whole compute unit).  AUTO 16 */
+  int32_t cu_walkers;         /* CU: waves of a workgroup that walk (the rest only shade).  AUTO: 5/8 of them */
+  int32_t cu_flex;            /* CU: bit 0: a walking wave that holds no ray may run a vertex batch.  AUTO 1 */
+  int32_t cu_lowwater;        /* CU: partial vertex batches run only while fewer rays than this wait in the walk ring.  AUTO 64 */
+  int32_t cu_patience;        /* CU: looks in vain after which a wave takes a partial batch of any size.  AUTO 4 */
 } VimgHipOptions;
 /* Fills every field with VIMG_OPT_AUTO (and struct_size). */
 void vimg_hip_options_default(VimgHipOptions* opts);

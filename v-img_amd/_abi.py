@@ -124,8 +124,8 @@ class RenderStats(C.Structure):
 
 
 OPT_AUTO = -1
-SCHED_LANE, SCHED_POOL, SCHED_STAGE, SCHED_POOL4, SCHED_POOL4G = 1, 2, 3, 4, 5
-SCHEDULERS = {"lane": SCHED_LANE, "pool": SCHED_POOL, "stage": SCHED_STAGE, "pool4": SCHED_POOL4, "pool4g": SCHED_POOL4G}
+SCHED_LANE, SCHED_POOL, SCHED_STAGE, SCHED_POOL4, SCHED_POOL4G, SCHED_CU = 1, 2, 3, 4, 5, 6
+SCHEDULERS = {"lane": SCHED_LANE, "pool": SCHED_POOL, "stage": SCHED_STAGE, "pool4": SCHED_POOL4, "pool4g": SCHED_POOL4G, "cu": SCHED_CU}
 
 
 class HipOptions(C.Structure):
@@ -135,7 +135,8 @@ class HipOptions(C.Structure):
                 ("pool_refill", i32), ("pool_vbatch", i32), ("pool_classes", i32),
                 ("pool_starve", i32), ("pool_boxmin", i32), ("lds_leaf", i32),
                 ("stage_slots", i32), ("stage_seg_len", i32), ("stage_wchunk", i32),
-                ("stage_walk_quota", i32), ("pool4_rays", i32), ("lds_stack", i32), ("pool_gbreak", i32)]
+                ("stage_walk_quota", i32), ("pool4_rays", i32), ("lds_stack", i32), ("pool_gbreak", i32),
+                ("cu_waves", i32), ("cu_walkers", i32), ("cu_flex", i32), ("cu_lowwater", i32), ("cu_patience", i32)]
 
     def __init__(self, **kw):
         super().__init__()

@@ -129,6 +129,12 @@ struct RenderArgs {
   uint32_t pool_starve;             // pooled kernel: idle walk lanes (with no ray queued) that force a partial vertex batch
   uint32_t pool_gbreak;             // pool4 group build: a wave leaves the walk for a full batch only with this many rays or fewer in its lanes
   uint32_t pool_classes;            // pooled kernel: vertex queues: 1 = one, 2 = Principled apart, 3 = + Lambertian apart
+  uint32_t cu_walkers;              // CU scheduler: waves [0, cu_walkers) own traversal stacks and walk; the others only shade
+  uint32_t cu_flex;                 // CU scheduler: bit 0 = a walking wave that holds no ray may run a vertex batch
+  uint32_t cu_lowwater;             // CU scheduler: partial vertex batches only while fewer rays than this wait in the walk ring
+  uint32_t cu_patience;             // CU scheduler: looks in vain after which a wave takes a partial batch of any size
+  uint32_t cu_magic_v, cu_shift_v;  // CU scheduler: n / pool_slots == mulhi(n, magic) >> shift (n < 2^31)
+  uint32_t cu_magic_w, cu_shift_w;  // ... n / (2 * pool_slots)
   int32_t single_x, single_y;       // trace_pixel mode when >= 0
 };
 

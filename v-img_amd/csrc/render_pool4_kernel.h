@@ -39,7 +39,7 @@ VD Pool4KPtr pool4_kargs(uint32_t lo, uint32_t hi) {
       (static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(hi)))) << 32);
   return (Pool4KPtr)a;
 }
-__global__ void pool4_args_kernel(const Pool4KArgs ka, Pool4KArgs* __restrict__ dst) {
+static __global__ void pool4_args_kernel(const Pool4KArgs ka, Pool4KArgs* __restrict__ dst) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *dst = ka;
 }
 
@@ -110,9 +110,6 @@ VD Pool4GLayout pool4g_layout(VIMG_LDS uint32_t* pool, uint32_t PS) {
 __host__ __device__ constexpr uint32_t pool4g_group_bytes(uint32_t slots_per_wave) {
   return P4G_LDS_BYTES * 4u * slots_per_wave + 64u + 4u * 64u * 2u;
 }
-// rows of a lane's LDS stack: all entries, or the first stack_lds and one more that takes the
-// writes of the entries kept in global memory
-__host__ __device__ constexpr uint32_t pool4_stack_rows_of(uint32_t entries, uint32_t in_lds) { return in_lds < entries ? in_lds + 1u : entries; }
 // diagnostics of full-stats launches (VIMG_HIP_DIAG prints them): cycles in vertex calls by class
 // (0 finisher, 1 Lambertian, 2 Principled, 3 other), in the walk stage (4) and idle (5); batches and
 // slots per class
@@ -125,15 +122,6 @@ struct Pool4Diag {
 // = 28 % more slots, and the slot count is what this scheduler's rate hangs on: 64 slots 6.1,
 // 80: 8.1, 102: 9.7 Grays/s on config 2 at four waves per SIMD).
 constexpr uint32_t P4_LDS_BYTES = P4_HOT * 16u + 4u + 5u;
-// Cold records of a slot: the four every vertex batch reads and writes are ONE aligned 64-byte
-// line, [slot][4] (throughput, result, NEE term, RNG); the pixel accumulator (finisher batches
-// only) and the ray cone (textured build only) live in planes of their own behind them, so that a
-// vertex batch moves one line per slot and not two (measured with five records per slot in one
-// 80-byte block: 1.4 TB of L2 <-> fabric traffic per frame, four times the 64-byte layout's).
-constexpr uint32_t SC4_RNG = 3u;                     // rng lo | rng hi | px + (py << 16) | sample index  (replaces SC_ACC's place)
-constexpr uint32_t SC4_MAIN = 4u;                    // SC_THROUGHPUT, SC_RESULT, SC_NEE, SC4_RNG
-// 16-byte records per slot in a wave's cold region: main line + accumulator + cone
-__host__ __device__ constexpr uint32_t pool4_cold_records(bool tex) { return SC4_MAIN + 1u + (tex ? 1u : 0u); }
 VD uint32_t pool4_wave_bytes(uint32_t slots) { return (P4_LDS_BYTES * slots + 15u) & ~15u; }
 VD uint32_t uni(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); }
 

@@ -35,36 +35,9 @@
 // Every path still executes exactly the reference's operations in the reference's order with its
 // own RNG stream, so results are bit-identical to render_kernel and to the oracle.
 #pragma once
-#include "render_kernels.h"
+#include "sched_common.h"
 
 namespace vimg {
-
-// Slot state: 16-byte records stored [record][slot], so that one ds_read_b128 / ds_write_b128 (LDS)
-// or one global dwordx4 access moves a whole record.
-enum : uint32_t {   // hot records, LDS
-  SR_ORIGIN = 0,   // o.xyz | shadow max_t            (after the walk .w = t of the hit)
-  SR_RAY,          // d.xyz (camera / BSDF ray) | flags
-  SR_SHADOW,       // shadow d.xyz | -               (after the walk: e0 e1 e2 inv_det of the hit)
-  SR_RNG,          // rng lo | rng hi | px + (py << 16) | sample index   (first thing a vertex needs)
-  SR_COUNT
-};
-enum : uint32_t {   // cold records, global memory
-  SC_THROUGHPUT = 0,   // throughput.xyz | eta_scale
-  SC_RESULT,           // bounce_result.xyz | prev_pdf
-  SC_NEE,              // unoccluded next-event contribution.xyz | -
-  SC_ACC,              // accumulated pixel radiance.xyz | work item id
-  SC_CONE,             // cone width | spread angle | - | -   (textured build only)
-  SC_COUNT
-};
-// LDS bytes per slot and wave: the hot records, the primitive id plane and five queue rings of
-// one-byte slot ids (a wave has at most 256 slots)
-constexpr uint32_t POOL_LDS_BYTES = SR_COUNT * 16u + 4u + 5u;
-VD uint32_t pool_wave_bytes(uint32_t slots) { return (POOL_LDS_BYTES * slots + 15u) & ~15u; }
-enum : uint32_t {
-  SF_PRIMARY = 1u, SF_NONSPEC = 2u, SF_HAS_S = 4u, SF_HAS_R = 8u, SF_OCCLUDED = 16u,
-  SF_FOUND = 32u, SF_FRESH = 64u, SF_KIND_SPHERE = 128u, SF_BOUNCE_SHIFT = 8u
-};
-constexpr uint32_t SLOT_IDLE = 0xffffffffu;
 
 // stage timers of the -DVIMG_PROFILE build (tools/stage_profile.py); nothing in the product build
 #ifdef VIMG_PROFILE
@@ -78,17 +51,6 @@ constexpr uint32_t SLOT_IDLE = 0xffffffffu;
 #define PROF_LAP(k)
 #define PROF_ADD(k, v)
 #endif
-
-// words of a pixel's between-segments record: agent-scope relaxed atomics (global_load/store sc1)
-VD void state_store(VIMG_GLOBAL uint32_t* p, uint32_t v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-VD uint32_t state_load(VIMG_GLOBAL uint32_t* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-VD uint32_t lane_rank(unsigned long long mask, uint32_t lane) {
-  return __popcll(mask & ((1ull << lane) - 1ull));
-}
 
 // DEEP: the tree does not fit the LDS node cache (deep, memory-resident trees): the box loop hands
 // over to the leaf loop as soon as fewer than pool_boxmin lanes still descend.  On trees that sit

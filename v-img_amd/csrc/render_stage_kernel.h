@@ -109,7 +109,7 @@ VD StageKPtr stage_kargs(uint32_t lo, uint32_t hi) {
       (static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(hi)))) << 32);
   return (StageKPtr)a;
 }
-__global__ void stage_args_kernel(const StageKArgs ka, StageKArgs* __restrict__ dst) {
+static __global__ void stage_args_kernel(const StageKArgs ka, StageKArgs* __restrict__ dst) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *dst = ka;
 }
 

@@ -16,10 +16,12 @@
 #include "../../include/vimg_hip.h"
 #include "post_kernels.h"
 #include "pre_kernels.h"
-#include "render_kernels.h"
+#include "aux_kernels.h"
+#include "kernel_tus.h"
 #include "render_pool_kernel.h"
 #include "render_stage_kernel.h"
 #include "render_pool4_kernel.h"
+#include "render_cu_kernel.h"
 #include "heatmap_kernel.h"
 
 using namespace vimg;
@@ -232,7 +234,7 @@ void options_from_env(VimgHipOptions* o) {
   if (const char* e = getenv("VIMG_HIP_SCHED")) {
     const std::string v(e);
     o->scheduler = v == "lane" ? VIMG_SCHED_LANE : v == "pool" ? VIMG_SCHED_POOL : v == "stage" ? VIMG_SCHED_STAGE
-                 : v == "pool4" ? VIMG_SCHED_POOL4 : v == "pool4g" ? VIMG_SCHED_POOL4G : atoi(e);
+                 : v == "pool4" ? VIMG_SCHED_POOL4 : v == "pool4g" ? VIMG_SCHED_POOL4G : v == "cu" ? VIMG_SCHED_CU : atoi(e);
   }
   struct { const char* name; int32_t* field; } vars[] = {
       {"VIMG_HIP_WAVES_PER_SIMD", &o->waves_per_simd}, {"VIMG_HIP_LDS_BUDGET_KB", &o->lds_budget_kb},
@@ -243,7 +245,9 @@ void options_from_env(VimgHipOptions* o) {
       {"VIMG_HIP_STAGE_SLOTS", &o->stage_slots},       {"VIMG_HIP_STAGE_SEG_LEN", &o->stage_seg_len},
       {"VIMG_HIP_STAGE_WCHUNK", &o->stage_wchunk},     {"VIMG_HIP_STAGE_WALK_QUOTA", &o->stage_walk_quota},
       {"VIMG_HIP_POOL4_RAYS", &o->pool4_rays},             {"VIMG_HIP_LDS_STACK", &o->lds_stack},
-      {"VIMG_HIP_POOL_GBREAK", &o->pool_gbreak}};
+      {"VIMG_HIP_POOL_GBREAK", &o->pool_gbreak},       {"VIMG_HIP_CU_WAVES", &o->cu_waves},
+      {"VIMG_HIP_CU_WALKERS", &o->cu_walkers},         {"VIMG_HIP_CU_FLEX", &o->cu_flex},
+      {"VIMG_HIP_CU_LOWWATER", &o->cu_lowwater},       {"VIMG_HIP_CU_PATIENCE", &o->cu_patience}};
   for (auto& v : vars)
     if (const char* e = getenv(v.name)) *v.field = atoi(e);
 }
@@ -280,43 +284,19 @@ struct LaunchCfg {
   int rays;      // pool4: rays a lane walks at the same time (1; two measured slower and are not built)
   bool group;    // pool4: one pool and one set of queues per workgroup (VIMG_SCHED_POOL4G) instead of per wave
   bool deep;     // pooled / staged kernel: build whose box loop yields to waiting leaves (tree beyond the LDS node cache)
+  int cu_waves;  // CU scheduler: waves per workgroup (16 or 8)
 };
 
-using RenderKernel = void (*)(const DScene, const RenderArgs, float*, DeviceStats*, unsigned int*);
-using StageKernel = void (*)(const StageKArgs*);
-using Pool4Kernel = void (*)(const Pool4KArgs*);
-Pool4Kernel pick_pool4_kernel(const VimgDeviceScene* s, bool deep, int wps, bool group);
 RenderKernel pick_kernel(const VimgDeviceScene* s, bool pooled, int wps, bool deep) {
-  if (pooled) {
-    if (deep) {
-      if (s->textured) return wps >= 3 ? render_pool_kernel<true, 3, true> : render_pool_kernel<true, 2, true>;
-      return wps >= 3 ? render_pool_kernel<false, 3, true> : render_pool_kernel<false, 2, true>;
-    }
-    if (s->textured) return wps >= 3 ? render_pool_kernel<true, 3, false> : render_pool_kernel<true, 2, false>;
-    return wps >= 3 ? render_pool_kernel<false, 3, false> : render_pool_kernel<false, 2, false>;
-  }
-  if (s->textured) return wps >= 3 ? render_kernel<true, 3> : render_kernel<true, 2>;
-  return wps >= 3 ? render_kernel<false, 3> : render_kernel<false, 2>;
+  return pooled ? vimg_pool_kernel(s->textured, wps, deep) : vimg_lane_kernel(s->textured, wps);
 }
-StageKernel pick_stage_kernel(const VimgDeviceScene* s, bool deep) {
-  if (s->textured) return deep ? render_stage_kernel<true, true> : render_stage_kernel<true, false>;
-  return deep ? render_stage_kernel<false, true> : render_stage_kernel<false, false>;
-}
-template <int WPS, bool GRP>
-Pool4Kernel pool4_build(bool tex, bool deep) {
-  if (tex) return deep ? render_pool4_kernel<true, true, WPS, 1, GRP> : render_pool4_kernel<true, false, WPS, 1, GRP>;
-  return deep ? render_pool4_kernel<false, true, WPS, 1, GRP> : render_pool4_kernel<false, false, WPS, 1, GRP>;
-}
-// (two rays per lane - NC = 2, both stepped in one pass of the box loop - measured slower and is not
-// built: config 2 9.3 against 11.7 Grays/s at 64 spp, 228 B of scratch; the loop runs until the
-// last of 128 rays instead of 64 has reached a leaf, which costs more lanes than the interleaving
-// hides latency)
+StageKernel pick_stage_kernel(const VimgDeviceScene* s, bool deep) { return vimg_stage_kernel(s->textured, deep); }
 Pool4Kernel pick_pool4_kernel(const VimgDeviceScene* s, bool deep, int wps, bool group) {
-  if (group) return wps >= 4 ? pool4_build<4, true>(s->textured, deep) : pool4_build<3, true>(s->textured, deep);
-  if (wps >= 4) return pool4_build<4, false>(s->textured, deep);
-  return pool4_build<3, false>(s->textured, deep);
+  return vimg_pool4_kernel(s->textured, deep, wps, group);
 }
+CuKernel pick_cu_kernel(const VimgDeviceScene* s, bool deep, int nw) { return vimg_cu_kernel(s->textured, deep, nw); }
 const void* kernel_of(const VimgDeviceScene* s, const LaunchCfg& c) {
+  if (c.sched == VIMG_SCHED_CU) return reinterpret_cast<const void*>(pick_cu_kernel(s, c.deep, c.cu_waves));
   if (c.sched == VIMG_SCHED_STAGE) return reinterpret_cast<const void*>(pick_stage_kernel(s, c.deep));
   if (c.sched == VIMG_SCHED_POOL4) return reinterpret_cast<const void*>(pick_pool4_kernel(s, c.deep, c.wps, c.group));
   return reinterpret_cast<const void*>(pick_kernel(s, c.pooled, c.wps, c.deep));
@@ -336,10 +316,117 @@ uint32_t log2_of(uint32_t pow2) {
 
 // The policy of one launch.  `sched_override`: 0 = by options / policy, else the scheduler to build
 // the configuration for (the fall-back from a scheduler that cannot take this launch).
+// n / d == mulhi(n, magic) >> shift for every n < 2^31 (Granlund & Montgomery, "Division by invariant
+// integers using multiplication", fig. 4.1 with N = 31): the ring index of render_cu_kernel's tickets
+void magic_div(uint32_t d, uint32_t* magic, uint32_t* shift) {
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;   // ceil(log2 d), d >= 2
+  *magic = static_cast<uint32_t>((1ull << (31u + l)) / d + 1ull);
+  *shift = l - 1u;
+}
+
+// The launch of the CU-wide scheduler (render_cu_kernel.h): one workgroup of 16 waves per compute unit
+// (or two of 8), a pool of as many slots as the CU's LDS holds behind the top of the tree, the
+// walking waves' stacks and the rings - never more than the launch has pixels per workgroup.
+LaunchCfg make_launch_cu(const VimgDeviceScene* s, const VimgRenderParams* p, int sx, int sy) {
+  LaunchCfg c{};
+  const VimgHipOptions& o = s->opt;
+  const uint64_t items = (sx >= 0) ? 1 : uint64_t(local_tiles(s, p)) * 64u;
+  c.sched = VIMG_SCHED_CU;
+  c.pooled = true;
+  c.group = false;
+  c.rays = 1;
+  c.wps = 4;
+  c.cu_waves = 16;   // (a build with two 8-wave workgroups per CU halves the pool a batch draws from; not built)
+  const uint32_t nw = uint32_t(c.cu_waves);
+  RenderArgs& a = c.args;
+  a.integrator = p->integrator;
+  a.samples = p->samples;
+  a.depth = p->depth;
+  a.tile_rank = p->tile_rank;
+  a.tile_world = p->tile_world;
+  a.tiles_x = tiles_of(s->d.res_x);
+  a.tiles_y = tiles_of(s->d.res_y);
+  a.num_local_tiles = local_tiles(s, p);
+  a.full_stats = 0;
+  a.single_x = sx;
+  a.single_y = sy;
+  a.stack_entries = s->d.max_depth + 2;
+  a.stack_lds = std::min(a.stack_entries, std::max(1u, opt_or(o.lds_stack, 32u)));
+  a.stack_ovf = nullptr;
+  // walking waves: five of eight by policy (config 2: the walk is 60 % of the wave cycles); when every
+  // wave walks, every wave must be allowed to shade too
+  a.cu_walkers = std::min(nw, std::max(1u, opt_or(o.cu_walkers, nw * 5u / 8u)));
+  a.cu_flex = opt_or(o.cu_flex, 1u) | (a.cu_walkers == nw ? 1u : 0u);
+  a.cu_lowwater = std::max(1u, opt_or(o.cu_lowwater, 64u));
+  a.cu_patience = opt_or(o.cu_patience, 4u);
+  a.pool_refill = std::max(1u, opt_or(o.pool_refill, 16u));
+  a.pool_vbatch = std::min(64u, std::max(1u, opt_or(o.pool_vbatch, 64u)));
+  a.pool_boxmin = std::min(64u, opt_or(o.pool_boxmin, 16u));
+  a.pool_starve = std::min(64u, std::max(1u, opt_or(o.pool_starve, 16u)));   // smallest partial batch worth a wave at once
+  a.pool_classes = std::min(3u, std::max(1u, opt_or(o.pool_classes, 3u)));
+  a.pool_gbreak = 0;
+  // LDS of the workgroup: the whole CU's (16 waves) or half of it, minus a margin
+  const uint32_t share = (160u * 1024u) / (16u / nw) - 1024u;
+  const uint32_t stack_rows = pool4_stack_rows_of(a.stack_entries, a.stack_lds);
+  const uint32_t stack_bytes = a.cu_walkers * stack_rows * 64u * 4u;
+  uint32_t node_budget = 4608u;
+  if (o.lds_budget_kb != VIMG_OPT_AUTO) node_budget = uint32_t(std::max(1, o.lds_budget_kb)) * 1024u;
+  a.lds_nodes = std::min(node_budget / 56u, s->d.num_nodes);
+  const uint32_t node_bytes = (a.lds_nodes * 56u + 255u) & ~255u;
+  // the build with the overflow path and the global node fetch serves both trees beyond the LDS
+  // node cache and stacks deeper than their LDS rows
+  c.deep = a.lds_nodes < s->d.num_nodes || a.stack_lds < a.stack_entries;
+  uint32_t leaf_bytes = 0;
+  a.lds_leaf = 0;
+  if (s->num_leaf_prims * 48u <= 4096u && o.lds_leaf != 0) {
+    a.lds_leaf = s->num_leaf_prims;
+    leaf_bytes = a.lds_leaf * 48u;
+  }
+  const uint32_t fixed = node_bytes + stack_bytes + cu_pool_bytes(0, nw) + leaf_bytes + 64u;
+  uint32_t slots = share > fixed ? (share - fixed) / CU_LDS_BYTES : 0u;
+  slots = std::min(slots, 4096u);
+  if (o.pool_slots != VIMG_OPT_AUTO) slots = std::min(slots, uint32_t(std::max(0, o.pool_slots)));
+  // never more slots than the launch has pixels per workgroup (a thin shard's pixels each own a slot
+  // from the first sample to the last)
+  const uint32_t groups = s->num_cus * (16u / nw);
+  const uint64_t per_group = (items + groups - 1) / groups;
+  slots = static_cast<uint32_t>(std::min<uint64_t>(slots, per_group + 8u));
+  slots = std::max(slots & ~7u, 8u);
+  a.pool_slots = slots;
+  magic_div(slots, &a.cu_magic_v, &a.cu_shift_v);
+  magic_div(2u * slots, &a.cu_magic_w, &a.cu_shift_w);
+  c.lds_bytes = node_bytes + stack_bytes + cu_pool_bytes(slots, nw) + leaf_bytes;
+  int per_cu = 0;
+  hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel_of(s, c), int(nw * 64u), c.lds_bytes);
+  if (oe != hipSuccess || per_cu < 1) per_cu = 1;
+  per_cu = std::min<int>(per_cu, int(16u / nw));
+  const uint64_t need_blocks = (items + slots - 1) / slots;
+  c.grid = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(need_blocks, uint64_t(s->num_cus) * per_cu)));
+  // segments: as the group build of render_pool4_kernel (the tail of a frame is one segment long)
+  a.pool_segments = 1;
+  a.pool_seg_len = p->samples;
+  if (sx < 0) {
+    const uint64_t in_flight = uint64_t(c.grid) * slots;
+    const double gens = double(items) / double(in_flight);
+    uint32_t k = gens >= 10.0 ? 1u : uint32_t(std::min(64.0, std::max(1.0, std::floor(176.0 / gens + 0.5))));
+    k = std::min<uint32_t>(k, std::max<uint32_t>(p->samples / 4u, 1u));
+    if (items * 2u < in_flight * 3u) k = 1u;
+    if (o.pool_segments != VIMG_OPT_AUTO) k = uint32_t(std::max(1, o.pool_segments));
+    k = std::min<uint32_t>(k, 4096u);
+    while (k > 1u && items * k >= 0xfff00000ull) --k;
+    const uint32_t len = std::max<uint32_t>((p->samples + k - 1) / k, 1u);
+    a.pool_seg_len = len;
+    a.pool_segments = std::max<uint32_t>((p->samples + len - 1) / len, 1u);
+  }
+  return c;
+}
+
 LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int sx, int sy,
                       bool for_render = true, int sched_override = 0, bool lds_stack_all = false) {
   LaunchCfg c{};
   const VimgHipOptions& o = s->opt;
+  if (for_render && !sched_override && o.scheduler == VIMG_SCHED_CU && !s->too_wide) return make_launch_cu(s, p, sx, sy);
   const uint64_t items = (sx >= 0) ? 1 : uint64_t(local_tiles(s, p)) * 64u;
   // ---- which scheduler.  Policy (AUTO): the pooled scheduler with its vertex stage as calls
   // (pool4); launches with too few pixels per wave for pools of 64 slots - test images,
@@ -561,9 +648,10 @@ int grow(void** p, size_t* have, size_t need) {
 int ensure_pool(VimgDeviceScene* s, LaunchCfg& c) {
   c.args.pool_cold = nullptr;
   if (!c.pooled || c.args.pool_slots == 0) return VIMG_OK;
-  const size_t ncold = (c.sched == VIMG_SCHED_POOL4) ? pool4_cold_records(s->textured)
-                                                      : (s->textured ? SC_COUNT : SC_COUNT - 1u);
-  const size_t need = size_t(c.grid) * 4u * ncold * c.args.pool_slots * 16u;
+  const bool cu = c.sched == VIMG_SCHED_CU;
+  const size_t ncold = (c.sched == VIMG_SCHED_POOL4 || cu) ? pool4_cold_records(s->textured)
+                                                            : (s->textured ? SC_COUNT : SC_COUNT - 1u);
+  const size_t need = size_t(c.grid) * (cu ? 1u : 4u) * ncold * c.args.pool_slots * 16u;
   if (need > s->pool_cold_bytes) {
     if (s->d_pool_cold) HIP_TRY(hipFree(s->d_pool_cold));
     s->d_pool_cold = nullptr;
@@ -574,7 +662,7 @@ int ensure_pool(VimgDeviceScene* s, LaunchCfg& c) {
   c.args.pool_cold = (VIMG_GLOBAL v4u*)s->d_pool_cold;
   if (c.args.stack_lds < c.args.stack_entries) {
     if (int rc = grow(&s->d_stack_ovf, &s->stack_ovf_bytes,
-                      size_t(c.grid) * 4u * uint32_t(c.rays) * (c.args.stack_entries - c.args.stack_lds) * 256u))
+                      size_t(c.grid) * (cu ? c.args.cu_walkers : 4u) * uint32_t(c.rays) * (c.args.stack_entries - c.args.stack_lds) * 256u))
       return rc;
     c.args.stack_ovf = (VIMG_GLOBAL uint32_t*)s->d_stack_ovf;
   }
@@ -662,7 +750,10 @@ int enqueue_render(VimgDeviceScene* s, const VimgRenderParams* p, float* d_out, 
     if (ev0) HIP_TRY(hipEventRecord(ev0, st));
     hipLaunchKernelGGL(pick_pool4_kernel(s, c.deep, c.wps, c.group), dim3(c.grid), dim3(256), c.lds_bytes, st,
                        static_cast<const Pool4KArgs*>(blk));
-  } else
+  } else if (c.sched == VIMG_SCHED_CU)
+    hipLaunchKernelGGL(pick_cu_kernel(s, c.deep, c.cu_waves), dim3(c.grid), dim3(uint32_t(c.cu_waves) * 64u), c.lds_bytes, st,
+                       CuKArgs{s->d, c.args, d_out, stats, s->d_counter});
+  else
     hipLaunchKernelGGL(pick_kernel(s, c.pooled, c.wps, c.deep), dim3(c.grid), dim3(256), c.lds_bytes, st, s->d, c.args,
                        d_out, stats, s->d_counter);
   if (ev1) HIP_TRY(hipEventRecord(ev1, st));
@@ -1033,8 +1124,11 @@ int vimg_hip_scene_upload_opts(const VimgScene* sc, const VimgHipOptions* opts, 
     s->opt.struct_size = sizeof(VimgHipOptions);
   }
   options_from_env(&s->opt);
-  if (s->opt.scheduler != VIMG_OPT_AUTO && (s->opt.scheduler < VIMG_SCHED_LANE || s->opt.scheduler > VIMG_SCHED_POOL4G))
+  if (s->opt.scheduler != VIMG_OPT_AUTO && (s->opt.scheduler < VIMG_SCHED_LANE || s->opt.scheduler > VIMG_SCHED_CU))
     return bail(fail(VIMG_E_INVALID, "options: unknown scheduler"));
+  if ((s->opt.scheduler == VIMG_SCHED_POOL || s->opt.scheduler == VIMG_SCHED_STAGE) && !vimg_has_dev_schedulers())
+    return bail(fail(VIMG_E_UNSUPPORTED, "options: the schedulers POOL and STAGE are reference implementations of the "
+                                         "development build (make dev), not part of this library"));
   s->too_wide = (cam.res_x > 65535 || cam.res_y > 65535);   // slots pack pixel coordinates in 16 bits
   hipDeviceProp_t prop{};
   if (hipGetDeviceProperties(&prop, g_device) != hipSuccess) return bail(fail(VIMG_E_DEVICE, "hipGetDeviceProperties failed"));
@@ -1076,6 +1170,9 @@ const char* vimg_hip_launch_kernel(const VimgDeviceScene* s, const VimgRenderPar
   const LaunchCfg c = make_launch(s, p, -1, -1);
   static const char* pool4_names[2][2] = {{"render_pool4_kernel<false>", "render_pool4_kernel<false,deep>"},
                                           {"render_pool4_kernel<true>", "render_pool4_kernel<true,deep>"}};   // (+ waves per SIMD, rays per lane)
+  static const char* cu_names[2][2] = {{"render_cu_kernel<false>", "render_cu_kernel<false,deep>"},
+                                       {"render_cu_kernel<true>", "render_cu_kernel<true,deep>"}};
+  if (c.sched == VIMG_SCHED_CU) return cu_names[s->textured ? 1 : 0][c.deep ? 1 : 0];
   if (c.sched == VIMG_SCHED_STAGE) return stage_names[s->textured ? 1 : 0][c.deep ? 1 : 0];
   static const char* pool4g_names[2][2] = {{"render_pool4_kernel<false,group>", "render_pool4_kernel<false,deep,group>"},
                                            {"render_pool4_kernel<true,group>", "render_pool4_kernel<true,deep,group>"}};
