@@ -56,6 +56,9 @@ DEVOBJ    := $(patsubst v-img_amd/csrc/%.hip,$(DEVOBJDIR)/%.o,$(HIPSRC))
 $(DEVOBJDIR)/k_dev.o: v-img_amd/csrc/k_dev.hip $(HIPHDR) Makefile
 	@mkdir -p $(DEVOBJDIR)
 	$(HIPCC) $(HIPCFLAGS) -DVIMG_DEV_SCHEDULERS=1 $< -o $@
+$(DEVOBJDIR)/k_pool4.o: v-img_amd/csrc/k_pool4.hip $(HIPHDR) Makefile
+	@mkdir -p $(DEVOBJDIR)
+	$(HIPCC) $(HIPCFLAGS) -DVIMG_DEV_SCHEDULERS=1 $< -o $@
 $(DEVOBJDIR)/%.o: $(OBJDIR)/%.o
 	@mkdir -p $(DEVOBJDIR)
 	cp $< $@
@@ -63,20 +66,6 @@ dev: v-img_amd/lib/dev/libvimg_hip.so
 v-img_amd/lib/dev/libvimg_hip.so: $(DEVOBJ)
 	@mkdir -p v-img_amd/lib/dev
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(DEVOBJ) -o $@
-
-# measurement build: stage timers (s_memtime) inside render_pool_kernel; never the product library,
-# selected with VIMG_HIP_LIB by tools/stage_profile.py
-prof: v-img_amd/lib/prof/libvimg_hip.so
-v-img_amd/lib/prof/libvimg_hip.so: $(HIPSRC) $(HIPHDR) Makefile
-	@mkdir -p v-img_amd/lib/prof
-	$(HIPCC) $(HIPFLAGS) -DVIMG_PROFILE=1 $(HIPSRC) -o $@
-
-# measurement build: cycle and trip counters inside the walk stage of render_pool4_kernel
-# (VIMG_HIP_DIAG=1 prints them after a stats launch); selected with VIMG_HIP_LIB by tools/walk_diag.sh
-diag: v-img_amd/lib/diag/libvimg_hip.so
-v-img_amd/lib/diag/libvimg_hip.so: $(HIPSRC) $(HIPHDR) Makefile
-	@mkdir -p v-img_amd/lib/diag
-	$(HIPCC) $(HIPFLAGS) -DVIMG_WALK_DIAG=1 $(HIPSRC) -o $@
 
 # C++ host program (the counterpart of the reference's main): links both libraries by rpath
 v-img_amd/bin/vimg-amd: v-img_amd/cli/main.cpp $(LIBDIR)/libvimg_host.so $(LIBDIR)/libvimg_hip.so Makefile
@@ -103,4 +92,4 @@ oracle/liboracle_avx2.so: $(ORASRC) $(ORAHDR) Makefile
 clean:
 	rm -rf $(LIBDIR)/*.so $(LIBDIR)/dev oracle/*.so build/hip build/hip_dev
 
-.PHONY: all host hip dev oracle oracle-avx2 cli clean prof diag
+.PHONY: all host hip dev oracle oracle-avx2 cli clean

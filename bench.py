@@ -268,6 +268,7 @@ def main():
         if n > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        dev.check()     # a frame the kernel's watchdog gave up is an error, not a measurement
         kernel_ms = sum(a.elapsed_time(b) for a, b in events) / steps
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=red_dev)
         if n > 1:

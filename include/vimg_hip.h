@@ -77,6 +77,8 @@ typedef struct VimgHipOptions {
   int32_t cu_flex;            /* CU: bit 0: a walking wave that holds no ray may run a vertex batch.  AUTO 1 */
   int32_t cu_lowwater;        /* CU: partial vertex batches run only while fewer rays than this wait in the walk ring.  AUTO 64 */
   int32_t cu_patience;        /* CU: looks in vain after which a wave takes a partial batch of any size.  AUTO 4 */
+  int32_t cu_join;            /* CU: queued rays at which a walking wave that holds no ray starts to walk (fewer: after cu_patience looks).  AUTO 1 */
+  int32_t cu_sleep;           /* CU: s_sleep argument (64 cycles each) of a wave that found nothing to do.  AUTO 4 */
 } VimgHipOptions;
 /* Fills every field with VIMG_OPT_AUTO (and struct_size). */
 void vimg_hip_options_default(VimgHipOptions* opts);
@@ -111,9 +113,15 @@ int vimg_hip_render(VimgDeviceScene* scene, const VimgRenderParams* params, void
  * back-to-back launches with HIP events on `stream`.  A scene renders one frame at a time: its
  * work counter and the scheduler's scratch (path-slot records, per-pixel records) are owned by the
  * scene, so launches on the same scene must be ordered on one stream.  A kernel-side failure (the
- * scheduler's watchdog) is reported by the next blocking call on the scene, not by this one. */
+ * scheduler's watchdog) is reported by the next blocking call on the scene or by vimg_hip_check, not by this one. */
 int vimg_hip_render_async(VimgDeviceScene* scene, const VimgRenderParams* params, void* d_out_rgb,
                           void* stream);
+
+/* The error word of the scene's launches since it was last read: VIMG_OK, or VIMG_E_DEVICE when a
+ * kernel's watchdog gave a frame up (the frame is then incomplete).  Blocking calls read it
+ * themselves; after vimg_hip_render_async the caller synchronises the stream and then asks here,
+ * before it uses, gathers or times the frame.  Reading clears the word. */
+int vimg_hip_check(VimgDeviceScene* scene);
 
 /* Convenience: tile_world must be 1; renders into an internal device buffer and copies the
  * W*H*3 floats to out_rgb_host (what a reference maintainer would call from main.cpp). */

@@ -89,100 +89,153 @@ def _dev_opts(scene, **opts):
     return hip.DeviceScene(scene, **opts)
 
 
-# scheduler configurations (VimgHipOptions): every one must give the lane-bound kernel's bits
+# scheduler configurations (VimgHipOptions) of the PRODUCT library: every one must give the lane-bound
+# kernel's bits.  (The schedulers of rounds 1 and 2 - pool, pool4, pool4g, stage - live in the
+# development build and are cross-checked there: test_dev_build_schedulers_give_the_same_bits.)
 SCHEDULES = {
     "lane": dict(scheduler="lane"),
+    # the CU-wide scheduler as the policy configures it
+    "cu": dict(scheduler="cu"),
+    # every pixel's samples cut into 5 segments that travel through per-pixel records in global memory;
+    # at test sizes far more slots are in flight than there are pixels, so slots constantly draw
+    # segments whose predecessor is still running (the waiting path)
+    "cu/5": dict(scheduler="cu", pool_segments=5),
+    # few slots per compute unit: several generations of pixels per slot, rings that wrap often
+    "cu/few": dict(scheduler="cu", pool_slots=64, pool_segments=2),
+    "cu/tiny": dict(scheduler="cu", pool_slots=8, pool_segments=3),
+    # every wave walks and shades / one wave walks / fifteen walk
+    "cu/w16": dict(scheduler="cu", cu_walkers=16),
+    "cu/w1": dict(scheduler="cu", cu_walkers=1, pool_segments=2),
+    "cu/w15": dict(scheduler="cu", cu_walkers=15, cu_flex=0),
+    # batches and refills as eager as they get; as patient as they get
+    "cu/eager": dict(scheduler="cu", pool_refill=1, pool_starve=1, cu_patience=0, cu_join=1, pool_vbatch=8),
+    "cu/patient": dict(scheduler="cu", pool_refill=48, pool_starve=64, cu_patience=64, cu_join=64, cu_sleep=32),
+    # one queue of shading vertices instead of one per material class; two
+    "cu/1class": dict(scheduler="cu", pool_classes=1),
+    "cu/2class": dict(scheduler="cu", pool_classes=2, pool_segments=2),
+    # only the first entries of a lane's traversal stack in LDS, the rest in global memory: one entry /
+    # three, so that nearly every push and pop takes that path (the build for trees beyond LDS)
+    "cu/stack1": dict(scheduler="cu", lds_stack=1),
+    "cu/stack3": dict(scheduler="cu", lds_stack=3, pool_segments=2),
+    # the top of the tree outside LDS too (one kilobyte of node cache), no leaf copy in LDS
+    "cu/nolds": dict(scheduler="cu", lds_budget_kb=1, lds_leaf=0),
+}
+# the same for the development build (tests/dev_schedulers.py)
+DEV_SCHEDULES = {
     "pool": dict(scheduler="pool"),
-    # the pooled kernel with every pixel's samples cut into 5 segments that travel through per-pixel
-    # records in global memory; at test sizes far more slots are in flight than there are pixels,
-    # so slots constantly draw segments whose predecessor is still running (the waiting path)
     "pool/5": dict(scheduler="pool", pool_segments=5),
     "pool/64": dict(scheduler="pool", pool_segments=64),
-    # the pooled scheduler with its vertex stage as calls, four waves per SIMD
     "pool4": dict(scheduler="pool4"),
     "pool4/5": dict(scheduler="pool4", pool_segments=5),
     "pool4/4": dict(scheduler="pool4", waves_per_simd=4, pool_segments=3),
-    # one pool and one set of queues per workgroup: the four waves take rays and batches from
-    # shared rings under a lock in LDS; with pixels cut into segments; with few slots per wave
     "pool4g": dict(scheduler="pool4g"),
     "pool4g/5": dict(scheduler="pool4g", pool_segments=5),
     "pool4g/few": dict(scheduler="pool4g", pool_slots=24, pool_segments=2),
-    # trees beyond LDS keep only the first entries of a lane's traversal stack in LDS and the rest
-    # in global memory: here one entry / three, so that nearly every push and pop takes that path
     "pool4/stack1": dict(scheduler="pool4", lds_stack=1),
     "pool4/stack3": dict(scheduler="pool4", lds_stack=3, pool_segments=2),
-    # the staged kernel: as many slots as pixels (policy), then far fewer slots than pixels so that
-    # pixels queue in the ready FIFO, one-sample and whole-pixel segments, the smallest walk chunk
     "stage": dict(scheduler="stage"),
     "stage/few": dict(scheduler="stage", stage_slots=300, stage_seg_len=1),
     "stage/whole": dict(scheduler="stage", stage_slots=1000, stage_seg_len=1 << 20, stage_walk_quota=128),
+}
+KERNEL_OF = {"lane": "render_kernel", "cu": "render_cu_kernel", "pool": "render_pool_kernel", "pool4": "render_pool4_kernel",
+             "pool4g": "render_pool4_kernel", "stage": "render_stage_kernel"}
+
+
+def scheduler_scene(scene_name):
+    if scene_name == "feature":
+        s = scenes.feature_scene(res=(72, 48), envmap=True, lens=True)
+        return s, s.default_params(samples=6, depth=7)
+    s = scenes.json_scene(scene_name, res=(136, 72))
+    return s, s.default_params(samples=12)
+
+
+def check_schedules_against_lane(s, p, schedules, what, twice=True):
+    """Every configuration of `schedules` renders the lane-bound kernel's bits and event counts
+    (a second launch on the same records and trace_pixel included when `twice`)."""
+    ref_dev = _dev_opts(s, scheduler="lane")
+    ref, rst = ref_dev.render_to_host(p)
+    ref_px = ref_dev.trace_pixel(p, 17, 23) if twice else None
+    for name, opts in schedules.items():
+        d = _dev_opts(s, **opts)
+        assert d.kernel.startswith(KERNEL_OF[opts["scheduler"]]), (name, d.kernel)
+        assert ("group" in d.kernel) == (opts["scheduler"] == "pool4g"), (name, d.kernel)
+        img, st = d.render_to_host(p)
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (what, name, d.kernel)
+        assert st.as_dict() == rst.as_dict(), (what, name)
+        if twice:
+            again, _ = d.render_to_host(p)            # a second launch on the same records
+            assert np.array_equal(img.view(np.uint32), again.view(np.uint32)), (what, name)
+            px = d.trace_pixel(p, 17, 23)
+            assert np.array_equal(np.asarray(px).view(np.uint32), np.asarray(ref_px).view(np.uint32)), (what, name)
+        d.close()
+    return ref, rst
+
+
+FEATURE_CASES = {
+    "config3": lambda: (scenes.config3_scene(res=(96, 72), env=(128, 64)), dict(samples=8, depth=12)),
+    "config4": lambda: (scenes.config4_scene(res=(96, 54), n_lat=48, env=(128, 64)), dict(samples=8, depth=12)),
+    "config5": lambda: (scenes.config5_scene(res=(96, 54), n=64, tex=64), dict(samples=8, depth=12)),
+    "big_mesh": lambda: (scenes.big_mesh_scene(res=(96, 64)), dict(samples=6)),
+    "cornell material": lambda: (scenes.json_scene("cornell_box_spheres.json", res=(80, 80)),
+                                 dict(samples=8, integrator="material", depth=16)),
+    "feature material": lambda: (scenes.feature_scene(res=(72, 48)), dict(samples=6, integrator="material", depth=8)),
+    "glass s_normal": lambda: (scenes.json_scene("glass_in_box.json", res=(96, 72)), dict(samples=4, integrator="s_normal")),
+    "disney g_normal": lambda: (scenes.json_scene("disney_spheres.json", res=(120, 56)), dict(samples=4, integrator="g_normal")),
+    "sphere lights": lambda: (scenes.json_scene("MIS_light_tests/sphere_light_medium_mis.json", res=(64, 64)), dict(samples=16)),
+    "const background light": lambda: (scenes.feature_scene(res=(72, 48), envmap=False, lens=False), dict(samples=6, depth=7)),
 }
 
 
 @pytest.mark.parametrize("scene_name", ["disney_spheres.json", "glass_in_box.json", "feature"])
 def test_all_schedulers_give_the_same_bits(scene_name):
-    """render_kernel (one path per lane), render_pool_kernel (paths pooled in LDS) and
-    render_stage_kernel (path state in HBM, stages coupled by queues) are three schedules of the
-    same per-path arithmetic: identical images, identical event counts, whichever the policy would
-    pick for the scene; trace_pixel and repeated launches on the same scratch included."""
-    if scene_name == "feature":
-        s = scenes.feature_scene(res=(72, 48), envmap=True, lens=True)
-        p = s.default_params(samples=6, depth=7)
-    else:
-        s = scenes.json_scene(scene_name, res=(136, 72))
-        p = s.default_params(samples=12)
-    out = {}
-    for name, opts in SCHEDULES.items():
-        d = _dev_opts(s, **opts)
-        assert d.kernel.startswith({"lane": "render_kernel", "pool": "render_pool_kernel", "pool4": "render_pool4_kernel",
-                                    "pool4g": "render_pool4_kernel", "stage": "render_stage_kernel"}[opts["scheduler"]]), (name, d.kernel)
-        assert ("group" in d.kernel) == (opts["scheduler"] == "pool4g"), (name, d.kernel)
-        img, st = d.render_to_host(p)
-        again, _ = d.render_to_host(p)            # a second launch on the same records
-        assert np.array_equal(img.view(np.uint32), again.view(np.uint32)), name
-        px = d.trace_pixel(p, 17, 23)
-        out[name] = (img, st, px)
-    a = out["lane"]
-    for other, o in out.items():
-        assert np.array_equal(a[0].view(np.uint32), o[0].view(np.uint32)), other
-        assert np.array_equal(np.asarray(a[2]).view(np.uint32), np.asarray(o[2]).view(np.uint32)), other
-        assert a[1].as_dict() == o[1].as_dict(), other
+    """render_kernel (one path per lane) and render_cu_kernel (paths pooled per compute unit, walking
+    and shading waves coupled by rings in LDS) in every configuration of SCHEDULES are schedules of
+    the same per-path arithmetic: identical images, identical event counts; trace_pixel and repeated
+    launches on the same scratch included; and the image is the oracle's."""
+    s, p = scheduler_scene(scene_name)
+    ref, rst = check_schedules_against_lane(s, p, SCHEDULES, scene_name)
     cpu, cst, _ = O.render(s, p)
-    _compare_images(out["stage"][0], cpu, scene_name + " (staged kernel)")
-    assert out["stage"][1].paths == cst.paths
+    _compare_images(ref, cpu, scene_name)
+    assert rst.paths == cst.paths
 
 
-@pytest.mark.parametrize("case", ["config3", "config4", "config5", "big_mesh", "cornell material",
-                                  "feature material", "glass s_normal", "disney g_normal",
-                                  "sphere lights", "const background light"])
-def test_pooled_and_staged_schedulers_on_every_feature(case):
-    """Frames of test size go to the lane-bound kernel by policy, so the other two schedulers are
-    asked for by name here on every feature the path has - image textures with mips, normal and RG
-    maps, env-map and constant-background lights, sphere lights, thin lens, deep trees (the DEEP
-    builds), the material and normal integrators - and must give the lane-bound kernel's bits and
-    event counts."""
-    mk = {
-        "config3": lambda: (scenes.config3_scene(res=(96, 72), env=(128, 64)), dict(samples=8, depth=12)),
-        "config4": lambda: (scenes.config4_scene(res=(96, 54), n_lat=48, env=(128, 64)), dict(samples=8, depth=12)),
-        "config5": lambda: (scenes.config5_scene(res=(96, 54), n=64, tex=64), dict(samples=8, depth=12)),
-        "big_mesh": lambda: (scenes.big_mesh_scene(res=(96, 64)), dict(samples=6)),
-        "cornell material": lambda: (scenes.json_scene("cornell_box_spheres.json", res=(80, 80)),
-                                     dict(samples=8, integrator="material", depth=16)),
-        "feature material": lambda: (scenes.feature_scene(res=(72, 48)), dict(samples=6, integrator="material", depth=8)),
-        "glass s_normal": lambda: (scenes.json_scene("glass_in_box.json", res=(96, 72)), dict(samples=4, integrator="s_normal")),
-        "disney g_normal": lambda: (scenes.json_scene("disney_spheres.json", res=(120, 56)), dict(samples=4, integrator="g_normal")),
-        "sphere lights": lambda: (scenes.json_scene("MIS_light_tests/sphere_light_medium_mis.json", res=(64, 64)), dict(samples=16)),
-        "const background light": lambda: (scenes.feature_scene(res=(72, 48), envmap=False, lens=False), dict(samples=6, depth=7)),
-    }[case]
-    s, kw = mk()
+@pytest.mark.parametrize("case", list(FEATURE_CASES))
+def test_cu_scheduler_on_every_feature(case):
+    """The CU scheduler in its corner configurations on every feature the path has - image textures
+    with mips, normal and RG maps, env-map and constant-background lights, sphere lights, thin lens,
+    deep trees (the DEEP builds), the material and normal integrators: the lane-bound kernel's bits
+    and event counts."""
+    s, kw = FEATURE_CASES[case]()
     p = s.default_params(**kw)
-    lane, st_lane = _dev_opts(s, scheduler="lane").render_to_host(p)
-    for name in ("pool", "pool/5", "pool4", "pool4/5", "pool4/4", "pool4/stack1", "pool4/stack3", "pool4g", "pool4g/5",
-                 "pool4g/few", "stage", "stage/few"):
-        d = _dev_opts(s, **SCHEDULES[name])
-        img, st = d.render_to_host(p)
-        assert np.array_equal(img.view(np.uint32), lane.view(np.uint32)), (case, name, d.kernel)
-        assert st.as_dict() == st_lane.as_dict(), (case, name)
+    pick = ("cu", "cu/5", "cu/few", "cu/tiny", "cu/w16", "cu/w1", "cu/eager", "cu/1class", "cu/stack1", "cu/stack3", "cu/nolds")
+    check_schedules_against_lane(s, p, {k: SCHEDULES[k] for k in pick}, case, twice=False)
+
+
+def test_dev_build_schedulers_give_the_same_bits():
+    """The schedulers of rounds 1 and 2 (render_pool_kernel, render_pool4_kernel per wave and per
+    workgroup, render_stage_kernel) are kept as reference implementations in the development build
+    of the library (make dev): ONE child process loads that build (VIMG_HIP_LIB) and checks every
+    configuration of DEV_SCHEDULES against the lane-bound kernel and the CU scheduler on the three
+    scheduler scenes and the ten feature cases (tests/dev_schedulers.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dev = os.path.join(root, "v-img_amd", "lib", "dev", "libvimg_hip.so")
+    assert os.path.exists(dev), "make dev"
+    env = dict(os.environ, VIMG_HIP_LIB=dev)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "dev_schedulers.py")], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert "DEV_SCHEDULERS OK" in r.stdout
+
+
+def test_product_library_refuses_the_retired_schedulers():
+    from vimg_amd import hip
+    s = scenes.json_scene("disney_spheres.json", res=(32, 16))
+    for name in ("pool", "pool4", "pool4g", "stage"):
+        with pytest.raises(hip.HipError, match="development build"):
+            _dev_opts(s, scheduler=name)
 
 
 @pytest.mark.parametrize("integrator", ["s_normal", "g_normal"])
@@ -217,7 +270,7 @@ def test_non_square_rg_map_reproduces_the_references_indexing():
     s = scenes.feature_scene(res=(96, 64), rg_shape=(32, 8))
     p = s.default_params(samples=8, depth=8)
     cpu, cst, _ = O.render(s, p)
-    for sched in ("lane", "pool4"):
+    for sched in ("lane", "cu"):
         gpu, gst = _dev_opts(s, scheduler=sched).render_to_host(p)
         _compare_images(gpu, cpu, f"wide RG map ({sched})", min_exact=0.995)
         assert gst.paths == cst.paths
@@ -340,7 +393,7 @@ def test_config4_and_5_standins_as_2_4_8_shards(name):
     """BASELINE configs[3] and [4] in the form they are stated - tile-sharded over 2 / 4 / 8 GPUs -
     on their stand-ins (deep trees, textures, normal / RG maps, HDRI + thin lens): every shard of
     every split rendered on this GPU (tile t -> rank t % N, include/integrators.h:57-65,101) with
-    the scheduler the policy picks for it, and with the pooled one asked for by name; the shards
+    the scheduler the policy picks for it, and with a small pool asked for by name; the shards
     reassemble, on the device, to the bits of the whole frame.  Stats add up exactly."""
     import torch
     from vimg_amd import dist as vdist
@@ -350,7 +403,7 @@ def test_config4_and_5_standins_as_2_4_8_shards(name):
     kw = dict(samples=6, depth=10)
     d = _dev(s)
     full, st_full = d.render(s.default_params(**kw))
-    pooled = _dev_opts(s, scheduler="pool4", pool_slots=40)
+    pooled = _dev_opts(s, scheduler="cu", pool_slots=40, pool_segments=2)
     for world in (2, 4, 8):
         for dev in (d, pooled):
             stride = vdist.shard_stride_pixels(w, h, world)
@@ -383,7 +436,7 @@ def test_config_standins_at_full_size_properties(name):
     assert (w, h) == ((1366, 1024) if name == "config3" else (1366, 768))
     p = s.default_params(samples=4, depth=16)
     d = _dev(s)
-    assert d.kernel.startswith("render_pool4_kernel")
+    assert d.kernel.startswith("render_cu_kernel")
     img, st = d.render_to_host(p)
     assert st.paths == w * h * 4 and st.nan_samples == 0
     assert np.isfinite(img).all() and img.min() >= 0
@@ -459,29 +512,24 @@ def test_full_size_properties_disney_spheres():
 
 
 def test_full_size_schedulers_and_segments_agree():
-    """BASELINE config 2 at full resolution: the policy launches the pooled scheduler in its
-    four-waves-per-SIMD build with the samples of a pixel cut into segments; the first pooled
-    kernel with its own segment policy and with seven segments, the staged kernel, the lane-bound
-    kernel and a thin shard all give the same bits.  Size-independent property: the image does not depend on scheduler, segment count or
-    shard count."""
+    """BASELINE config 2 at full resolution: the policy launches the CU scheduler with the samples of
+    a pixel cut into segments; the same with seven segments, with whole pixels, with a small pool,
+    the lane-bound kernel and a thin shard all give the same bits.  Size-independent property: the
+    image does not depend on scheduler, segment count, pool size or shard count."""
     s = scenes.json_scene("disney_spheres.json")
     p = s.default_params(samples=16)
     d = _dev(s)
-    assert d.kernel.startswith("render_pool4_kernel")
+    assert d.kernel.startswith("render_cu_kernel")
     auto, st_auto = d.render_to_host(p)
-    stage, st_stage = _dev_opts(s, scheduler="stage").render_to_host(p)
-    pool_dev = _dev_opts(s, scheduler="pool")
-    assert pool_dev.kernel.startswith("render_pool_kernel")
-    pool, st_pool = pool_dev.render_to_host(p)
-    seg, st_seg = _dev_opts(s, scheduler="pool", pool_segments=7).render_to_host(p)   # 16 samples in segments of 3 (+1)
+    seg, st_seg = _dev_opts(s, scheduler="cu", pool_segments=7).render_to_host(p)   # 16 samples in segments of 3 (+1)
+    whole, st_whole = _dev_opts(s, scheduler="cu", pool_segments=1).render_to_host(p)
+    small, st_small = _dev_opts(s, scheduler="cu", pool_slots=256, cu_walkers=12).render_to_host(p)
     lane_dev = _dev_opts(s, scheduler="lane")
     assert lane_dev.kernel.startswith("render_kernel")
     lane, st_lane = lane_dev.render_to_host(p)
-    assert np.array_equal(auto.view(np.uint32), lane.view(np.uint32))
-    assert np.array_equal(stage.view(np.uint32), lane.view(np.uint32))
-    assert np.array_equal(pool.view(np.uint32), lane.view(np.uint32))
-    assert np.array_equal(seg.view(np.uint32), lane.view(np.uint32))
-    assert st_auto.as_dict() == st_lane.as_dict() == st_seg.as_dict() == st_pool.as_dict() == st_stage.as_dict()
+    for img in (auto, seg, whole, small):
+        assert np.array_equal(img.view(np.uint32), lane.view(np.uint32))
+    assert st_auto.as_dict() == st_lane.as_dict() == st_seg.as_dict() == st_whole.as_dict() == st_small.as_dict()
     # an eighth of the frame (what one GPU of eight renders of the fixed frame)
     import torch
     from vimg_amd import dist as vdist
@@ -952,8 +1000,8 @@ def test_leaves_of_more_than_127_primitives(leaf_cap):
     biggest = max(bvh.nodes[i].obj_count for i in range(bvh.num_nodes))
     assert biggest > 127 and (biggest == n) == (leaf_cap > n)
     cpu, cst, _ = O.render(s, p)
-    for sched in ("lane", "pool4"):
-        gpu, gst = _dev_opts(s, scheduler=sched, **({"pool_slots": 40} if sched == "pool4" else {})).render_to_host(p)
+    for sched in ("lane", "cu"):
+        gpu, gst = _dev_opts(s, scheduler=sched, **({"pool_slots": 40} if sched == "cu" else {})).render_to_host(p)
         _compare_images(gpu, cpu, f"leaves of up to {biggest} primitives ({sched})", min_exact=0.995)
         assert gst.paths == cst.paths and gst.rays == cst.rays and gst.prim_tests <= cst.prim_tests
         assert gst.internal_visits > cst.internal_visits          # the chains' links
@@ -962,24 +1010,22 @@ def test_leaves_of_more_than_127_primitives(leaf_cap):
 
 
 def test_launch_policy_picks_the_builds_design_md_names():
-    """vimg_hip.hip:make_launch: a full frame on a tree in LDS gets the group build
-    (four waves per SIMD), thin shards of it the group build too and very thin ones the lane-bound
-    kernel; a tree in global memory gets the group build at every shard width; trace_pixel always the
-    lane-bound kernel.  (What each of them renders is the business of the parity tests above.)"""
+    """vimg_hip.hip:make_launch: every launch - a full frame, its shards down to an
+    eighth, a frame of test size, trace_pixel - gets the CU scheduler, in the build for trees that sit
+    in LDS or the one for trees in global memory; the lane-bound kernel by name.  (What each of them
+    renders is the business of the parity tests above.)"""
     s = scenes.json_scene("disney_spheres.json")                       # 1800 x 800
     d = _dev(s)
-    assert d.kernel_for(s.default_params(samples=4)) == "render_pool4_kernel<false,group>"
-    assert d.kernel_for(s.default_params(samples=4, tile_world=2)) == "render_pool4_kernel<false,group>"
-    assert d.kernel_for(s.default_params(samples=4, tile_world=4)) == "render_pool4_kernel<false,group>"
-    assert d.kernel_for(s.default_params(samples=4, tile_world=8)).startswith("render_kernel<false")
+    for tw in (1, 2, 4, 8):
+        assert d.kernel_for(s.default_params(samples=4, tile_world=tw)) == "render_cu_kernel<false>", tw
     small = _dev(scenes.json_scene("disney_spheres.json", res=(136, 72)))
-    assert small.kernel_for(s.default_params(samples=4)).startswith("render_kernel<false")
+    assert small.kernel_for(s.default_params(samples=4)) == "render_cu_kernel<false>"
     deep = scenes.config4_scene(n_lat=48, env=(128, 64))               # 1366 x 768, tree beyond LDS
     dd = _dev(deep)
     for tw in (1, 2, 4, 8):
-        assert dd.kernel_for(deep.default_params(samples=4, tile_world=tw)) == "render_pool4_kernel<true,deep,group>", tw
-    by_name = _dev_opts(s, scheduler="pool4")
-    assert by_name.kernel_for(s.default_params(samples=4)) == "render_pool4_kernel<false>"
+        assert dd.kernel_for(deep.default_params(samples=4, tile_world=tw)) == "render_cu_kernel<true,deep>", tw
+    by_name = _dev_opts(s, scheduler="lane")
+    assert by_name.kernel_for(s.default_params(samples=4)).startswith("render_kernel<false")
 
 
 def test_a_tree_deeper_than_the_lds_stack():
@@ -1028,8 +1074,9 @@ def test_a_tree_deeper_than_the_lds_stack():
     for k in ("closest_rays", "shadow_rays", "internal_visits", "leaf_visits", "prim_tests"):
         a, b = getattr(lst, k), getattr(cst, k)
         assert abs(a - b) <= max(64, 1e-3 * b), (k, a, b)
-    for sched in ("pool4", "pool4g"):
-        d = _dev_opts(s, scheduler=sched)
+    for opts in (dict(scheduler="cu"), dict(scheduler="cu", lds_stack=4, pool_segments=2)):
+        d = _dev_opts(s, **opts)
+        sched = str(opts)
         assert "deep" in d.kernel, d.kernel
         gpu, gst = d.render_to_host(p)
         assert np.array_equal(gpu.view(np.uint32), lane.view(np.uint32)), (sched, d.kernel)

@@ -136,7 +136,8 @@ class HipOptions(C.Structure):
                 ("pool_starve", i32), ("pool_boxmin", i32), ("lds_leaf", i32),
                 ("stage_slots", i32), ("stage_seg_len", i32), ("stage_wchunk", i32),
                 ("stage_walk_quota", i32), ("pool4_rays", i32), ("lds_stack", i32), ("pool_gbreak", i32),
-                ("cu_waves", i32), ("cu_walkers", i32), ("cu_flex", i32), ("cu_lowwater", i32), ("cu_patience", i32)]
+                ("cu_waves", i32), ("cu_walkers", i32), ("cu_flex", i32), ("cu_lowwater", i32), ("cu_patience", i32),
+                ("cu_join", i32), ("cu_sleep", i32)]
 
     def __init__(self, **kw):
         super().__init__()
@@ -201,6 +202,7 @@ HIP_SYMBOLS = {
     "vimg_hip_shard_pixels": (i64, [C.c_void_p, PParams]),
     "vimg_hip_render": (C.c_int, [C.c_void_p, PParams, C.c_void_p, C.c_void_p, PStats]),
     "vimg_hip_render_async": (C.c_int, [C.c_void_p, PParams, C.c_void_p, C.c_void_p]),
+    "vimg_hip_check": (C.c_int, [C.c_void_p]),
     "vimg_hip_render_to_host": (C.c_int, [C.c_void_p, PParams, Pf32, PStats]),
     "vimg_hip_trace_pixel": (C.c_int, [C.c_void_p, PParams, C.c_int, C.c_int, Pf32]),
     "vimg_hip_render_heatmap": (C.c_int, [C.c_void_p, PParams, f32, C.c_void_p, C.c_void_p]),

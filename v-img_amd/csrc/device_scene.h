@@ -133,6 +133,8 @@ struct RenderArgs {
   uint32_t cu_flex;                 // CU scheduler: bit 0 = a walking wave that holds no ray may run a vertex batch
   uint32_t cu_lowwater;             // CU scheduler: partial vertex batches only while fewer rays than this wait in the walk ring
   uint32_t cu_patience;             // CU scheduler: looks in vain after which a wave takes a partial batch of any size
+  uint32_t cu_join;                 // CU scheduler: queued rays at which a walking wave that holds none starts to walk (fewer: after cu_patience looks)
+  uint32_t cu_sleep;                // CU scheduler: s_sleep argument of a wave that found nothing to do
   uint32_t cu_magic_v, cu_shift_v;  // CU scheduler: n / pool_slots == mulhi(n, magic) >> shift (n < 2^31)
   uint32_t cu_magic_w, cu_shift_w;  // ... n / (2 * pool_slots)
   int32_t single_x, single_y;       // trace_pixel mode when >= 0
@@ -144,6 +146,9 @@ struct DeviceStats {
   // -DVIMG_PROFILE builds only (make prof): s_memtime cycles of wave 0.. summed over waves, per
   // stage of render_pool_kernel, and lanes switched on per vertex batch
   unsigned long long prof[28];
+  unsigned long long wait_cyc[5], wait_n[5];   // render_cu_kernel, statistics launches: cycles slots waited in the rings (vertex 0-3, walk), and how many
+  unsigned long long px_done[3];    // render_cu_kernel, statistics launches: when pixels finished (10 ns ticks since their workgroup started): sum, count, latest
+  unsigned long long walk_cyc[4];   // render_cu_kernel, statistics launches: cycles of the walk sessions in refill + set-up, box loop, leaf rounds, hand-over
 };
 enum : int { PF_TOTAL = 0, PF_V_LOAD, PF_V_LIGHT, PF_V_SAMPLE, PF_V_EVAL, PF_V_FINISH, PF_V_STORE,
              PF_W_REFILL, PF_W_BOX, PF_W_LEAF, PF_W_RETIRE, PF_V_BATCHES, PF_V_LANES, PF_V_ATVERTEX,

@@ -1,5 +1,8 @@
-// render_pool4_kernel: pools per wave / per workgroup with the vertex stage as calls (round 2's default)
+// render_pool4_kernel: pools per wave / per workgroup with the vertex stage as calls (round 2's default).
+// Since render_cu_kernel no launch policy picks it: like the other retired schedulers it is built
+// into the development library only (make dev), where the GPU tests cross-check it.
 #include "kernel_tus.h"
+#ifdef VIMG_DEV_SCHEDULERS
 #include "render_pool4_kernel.h"
 
 namespace vimg {
@@ -17,3 +20,8 @@ Pool4Kernel vimg_pool4_kernel(bool tex, bool deep, int wps, bool group) {
   return wps >= 4 ? pool4_build<4, false>(tex, deep) : pool4_build<3, false>(tex, deep);
 }
 }  // namespace vimg
+#else
+namespace vimg {
+Pool4Kernel vimg_pool4_kernel(bool, bool, int, bool) { return nullptr; }
+}  // namespace vimg
+#endif

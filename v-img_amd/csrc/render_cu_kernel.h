@@ -45,20 +45,26 @@ enum : uint32_t {
 };
 constexpr uint32_t CU_EMPTY = 0xffffu;   // ring entry nobody has written yet
 constexpr uint32_t CU_RAY_S = 0x8000u;   // walk-ring entry: the SHADOW ray of the slot (else its path ray)
-constexpr uint32_t CQ_WALK = 4u;
+// Rings: 0-3 vertex rings by class (0 finishers, 1 Lambertian, 2 Principled, 3 other), 4 the walk ring.
+// (Tried and removed: a second, URGENT set of rings for slots whose pixel lags behind the pool's mean
+// sample index, emptied first by every consumer.  On thin shards of config 2 the last pixel finished
+// no earlier - 19.2 against 18.4 ms at 64 spp on an eighth of the frame: the pixels a thin shard ends
+// with are bound by the service time of their hops, not by queueing - and the full frame paid 7 %
+// for the second set of pops and ballots: 325 against 304 ms.)
+constexpr uint32_t CQ_WALK = 4u, CQ_COUNT = 5u;
 // LDS bytes per slot: hot records, {primitive id, t} of the hit, four vertex rings (capacity P),
-// the walk ring (capacity 2 P: two rays per slot)
-constexpr uint32_t CU_LDS_BYTES = CR_COUNT * 16u + 8u + 4u * 2u + 2u * 2u;
+// the walk ring (capacity 2 P: two rays per slot), time of the last hand-over (statistics launches)
+constexpr uint32_t CU_LDS_BYTES = CR_COUNT * 16u + 8u + 4u * 2u + 2u * 2u + 4u;
 
 // queue state of the workgroup, in LDS
 struct CuCtl {
-  int32_t avail[4];        // entries ready in the vertex rings (one ds_read_b128)
-  int32_t avail_w;         // ... in the walk ring
+  int32_t avail[8];        // entries ready in ring q (0-3: one ds_read_b128; 4: the walk ring)
+  uint32_t tail[CQ_COUNT], head[CQ_COUNT];   // monotonic ticket counters (index = counter mod capacity)
   uint32_t live;           // slots that have not retired
   uint32_t pixels_left;    // the global work counter still had items last time
   uint32_t abort;
-  uint32_t tail[5], head[5];   // monotonic ticket counters (index = counter mod capacity)
-  uint32_t pad[6];
+  uint32_t t0_lo, t0_hi;   // s_memrealtime at the start of the workgroup (statistics launches)
+  uint32_t pad[1];
 };
 static_assert(sizeof(CuCtl) == 96, "CuCtl layout");
 // per wave, in LDS: what only statistics launches touch (event counts beyond the two ray counts,
@@ -66,8 +72,12 @@ static_assert(sizeof(CuCtl) == 96, "CuCtl layout");
 struct CuWaveRec {
   unsigned long long cyc[6], nbatch[4], nslots[4];
   uint32_t internal, leaf, prim, sphere;
+  unsigned long long box_pass, box_lanes, leaf_round, leaf_lanes, sessions, refills, refill_rays, pad;
+  unsigned long long looks, q_sum[4];   // looks of the main loop and the ring counts they saw (finisher, Lambertian, Principled, walk)
+  unsigned long long w_cyc[4];          // cycles of a walk session: refill + set-up, box loop, leaf rounds, hand-over
+  unsigned long long wait_cyc[5], wait_n[5];   // cycles slots spent in the rings (vertex 0-3, walk) and how many
 };
-static_assert(sizeof(CuWaveRec) == 128, "CuWaveRec layout");
+static_assert(sizeof(CuWaveRec) == 344, "CuWaveRec layout");
 __host__ __device__ constexpr uint32_t cu_pool_bytes(uint32_t slots, uint32_t waves) {
   return CU_LDS_BYTES * slots + uint32_t(sizeof(CuCtl)) + waves * uint32_t(sizeof(CuWaveRec));
 }
@@ -132,7 +142,8 @@ VD CuKPtr cu_kargs() {
   [[maybe_unused]] VIMG_LDS v2u* hitx = reinterpret_cast<VIMG_LDS v2u*>(recs + CR_COUNT * P);                           \
   [[maybe_unused]] VIMG_LDS uint16_t* ring_v = reinterpret_cast<VIMG_LDS uint16_t*>(hitx + P);                          \
   [[maybe_unused]] VIMG_LDS uint16_t* ring_w = ring_v + 4u * P;                                                         \
-  [[maybe_unused]] VIMG_LDS CuCtl* G = reinterpret_cast<VIMG_LDS CuCtl*>(ring_w + 2u * P);                              \
+  [[maybe_unused]] VIMG_LDS uint32_t* tq = reinterpret_cast<VIMG_LDS uint32_t*>(ring_w + 2u * P);                       \
+  [[maybe_unused]] VIMG_LDS CuCtl* G = reinterpret_cast<VIMG_LDS CuCtl*>(tq + P);                                       \
   [[maybe_unused]] VIMG_LDS CuWaveRec* wrec = reinterpret_cast<VIMG_LDS CuWaveRec*>(G + 1) + wave;                      \
   [[maybe_unused]] VIMG_LDS v4f* lds_leaf = reinterpret_cast<VIMG_LDS v4f*>(reinterpret_cast<VIMG_LDS CuWaveRec*>(G + 1) + NW); \
   [[maybe_unused]] VIMG_LDS uint32_t* recw = reinterpret_cast<VIMG_LDS uint32_t*>(recs);                                \
@@ -143,6 +154,9 @@ VD CuKPtr cu_kargs() {
   [[maybe_unused]] auto uf = [](uint32_t u) { return __uint_as_float(u); };                                             \
   [[maybe_unused]] auto mod_v = [&](uint32_t t) { return cu_mod(t, P, A.cu_magic_v, A.cu_shift_v); };                   \
   [[maybe_unused]] auto mod_w = [&](uint32_t t) { return cu_mod(t, 2u * P, A.cu_magic_w, A.cu_shift_w); };              \
+  [[maybe_unused]] auto ring_at = [&](uint32_t q, uint32_t t) -> VIMG_LDS uint16_t* {                                   \
+    return q >= CQ_WALK ? ring_w + mod_w(t) : ring_v + q * P + mod_v(t);                                                \
+  };                                                                                                                    \
   [[maybe_unused]] const bool leaf_in_lds = A.lds_leaf != 0u;                                                           \
   [[maybe_unused]] const uint32_t box_min = A.pool_boxmin;                                                              \
   /* cold records of the workgroup's slots in global memory: [slot][4] main lines (throughput, result, NEE term, RNG),  \
@@ -159,7 +173,7 @@ VD CuKPtr cu_kargs() {
   };                                                                                                                    \
   /* push: the lanes of `mask` append `entry`; the entries become visible to consumers with the add to the ring's      \
      count (LDS operations of one wave are performed in order) */                                                       \
-  [[maybe_unused]] auto push = [&](uint32_t q, VIMG_LDS uint16_t* ring, bool is_walk, unsigned long long mask, uint32_t entry) { \
+  [[maybe_unused]] auto push = [&](uint32_t q, unsigned long long mask, uint32_t entry) {                               \
     const uint32_t n_ = static_cast<uint32_t>(__popcll(mask));                                                          \
     if (n_ == 0u) return;                                                                                               \
     uint32_t t_ = 0;                                                                                                    \
@@ -168,20 +182,16 @@ VD CuKPtr cu_kargs() {
       if (t_ > 0x7ff00000u) raise(8u); /* the modulo is exact below 2^31 pushes per ring and launch */                  \
     }                                                                                                                   \
     t_ = cu_uni(t_);                                                                                                    \
-    if ((mask >> lane) & 1ull) {                                                                                        \
-      const uint32_t i_ = t_ + lane_rank(mask, lane);                                                                   \
-      ring[is_walk ? mod_w(i_) : mod_v(i_)] = static_cast<uint16_t>(entry);                                             \
-    }                                                                                                                   \
+    if ((mask >> lane) & 1ull) *ring_at(q, t_ + lane_rank(mask, lane)) = static_cast<uint16_t>(entry);                  \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                                                              \
-    if (lane == 0) lds_add_rtn(is_walk ? &G->avail_w : &G->avail[q], static_cast<int32_t>(n_));                         \
+    if (lane == 0) lds_add_rtn(&G->avail[q], static_cast<int32_t>(n_));                                                 \
   };                                                                                                                    \
   /* pop: up to `want` entries (wave-uniform); the lanes of `takers` (at least `want` of them) receive them in rank    \
      order; returns the number taken.  An entry whose producer has reserved but not yet written reads EMPTY. */         \
-  [[maybe_unused]] auto pop = [&](uint32_t q, VIMG_LDS uint16_t* ring, bool is_walk, uint32_t want, unsigned long long takers, \
-                                  uint32_t& entry) -> uint32_t {                                                        \
+  [[maybe_unused]] auto pop = [&](uint32_t q, uint32_t want, unsigned long long takers, uint32_t& entry) -> uint32_t {   \
     uint32_t got_ = 0, h_ = 0;                                                                                          \
     if (lane == 0) {                                                                                                    \
-      VIMG_LDS int32_t* av_ = is_walk ? &G->avail_w : &G->avail[q];                                                     \
+      VIMG_LDS int32_t* av_ = &G->avail[q];                                                                             \
       const int32_t old_ = lds_add_rtn(av_, -static_cast<int32_t>(want));                                               \
       const int32_t g2_ = old_ < 0 ? 0 : (old_ < static_cast<int32_t>(want) ? old_ : static_cast<int32_t>(want));       \
       if (g2_ < static_cast<int32_t>(want)) lds_add_rtn(av_, static_cast<int32_t>(want) - g2_);                         \
@@ -195,7 +205,7 @@ VD CuKPtr cu_kargs() {
     if ((takers >> lane) & 1ull) {                                                                                      \
       const uint32_t r_ = lane_rank(takers, lane);                                                                      \
       if (r_ < got_) {                                                                                                  \
-        VIMG_LDS uint16_t* e_ = ring + (is_walk ? mod_w(h_ + r_) : mod_v(h_ + r_));                                     \
+        VIMG_LDS uint16_t* e_ = ring_at(q, h_ + r_);                                                                    \
         uint32_t v_ = __hip_atomic_load(e_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), spins_ = 0;                \
         while (v_ == CU_EMPTY && !stuck_) {                                                                             \
           __builtin_amdgcn_s_sleep(1);                                                                                  \
@@ -531,6 +541,11 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan)
         out[o + 1] = px_col.y;
         out[o + 2] = px_col.z;
         need_pixel = true;
+        if (full_stats) {   // when pixels finish, in 10 ns ticks since the workgroup started: sum, count, latest
+          const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - (static_cast<unsigned long long>(G->t0_lo) | (static_cast<unsigned long long>(G->t0_hi) << 32));
+          DeviceStats* __restrict__ stp = K->stats;
+          if (stp) atomicAdd(&stp->px_done[0], dt), atomicAdd(&stp->px_done[1], 1ull), atomicMax(&stp->px_done[2], dt);
+        }
       } else if (n_seg > 1u && smp % seg_len == 0u) {
         // end of a segment: the pixel rests in its record until a slot draws its next segment
         // (words written and read with agent-scope relaxed atomics: data, wait, then the tag)
@@ -647,13 +662,13 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan)
     if (finisher_batch) cold_acc[slot] = v4u{fu(acc.x), fu(acc.y), fu(acc.z), item};
     if constexpr (TEX) cold_cone[slot] = v4u{fu(cone.cone_width), fu(cone.spread_angle), 0u, 0u};
   }
+  if (full_stats && keep) tq[slot] = static_cast<uint32_t>(__builtin_readcyclecounter());
   // the next stage of a slot may run on another wave of the CU: its cold records must have left
   // this wave before the slot id does (same L1: performed = visible)
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   {
-    const unsigned long long ms = __ballot(keep && has_s), mr = __ballot(keep && has_r);
-    const unsigned long long mfin = __ballot(keep && !has_s && !has_r);
     // one reservation for both kinds of ray: shadow rays first (an occluded one is the shorter walk)
+    const unsigned long long ms = __ballot(keep && has_s), mr = __ballot(keep && has_r);
     const uint32_t n_s = static_cast<uint32_t>(__popcll(ms)), n_r = static_cast<uint32_t>(__popcll(mr));
     if (n_s + n_r != 0u) {
       uint32_t t = 0;
@@ -662,12 +677,13 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan)
         if (t > 0x7ff00000u) raise(8u);
       }
       t = cu_uni(t);
-      if (keep && has_s) ring_w[mod_w(t + lane_rank(ms, lane))] = static_cast<uint16_t>(slot | CU_RAY_S);
-      if (keep && has_r) ring_w[mod_w(t + n_s + lane_rank(mr, lane))] = static_cast<uint16_t>(slot);
+      if (keep && has_s) *ring_at(CQ_WALK, t + lane_rank(ms, lane)) = static_cast<uint16_t>(slot | CU_RAY_S);
+      if (keep && has_r) *ring_at(CQ_WALK, t + n_s + lane_rank(mr, lane)) = static_cast<uint16_t>(slot);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) lds_add_rtn(&G->avail_w, static_cast<int32_t>(n_s + n_r));
+      if (lane == 0) lds_add_rtn(&G->avail[CQ_WALK], static_cast<int32_t>(n_s + n_r));
     }
-    push(0u, ring_v, false, mfin, slot);
+    // a path that ended here goes to the finisher ring; so do slots that wait for a segment
+    push(0u, __ballot(keep && !has_s && !has_r), slot);
     const uint32_t n_retired = static_cast<uint32_t>(__popcll(__ballot(on && retire)));
     if (n_retired && lane == 0) __hip_atomic_fetch_sub(&G->live, n_retired, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
@@ -694,18 +710,32 @@ VD void cu_walk(uint32_t& n_closest, uint32_t& n_shadow) {
   rec.prim = 0xffffffffu, rec.kind = 0;
   rec.e0 = rec.e1 = rec.e2 = rec.inv_det = 0.f;
   uint32_t c_internal = 0, c_leaf = 0, c_prim = 0, c_sphere = 0;   // per-lane event counts of statistics launches
+  uint32_t d_box = 0, d_boxl = 0, d_leaf = 0, d_leafl = 0, d_ref = 0, d_refr = 0;   // wave-uniform: passes and lanes (statistics launches)
+  unsigned long long wt = full_stats ? __builtin_readcyclecounter() : 0ull, wc0 = 0, wc1 = 0, wc2 = 0, wc3 = 0;
+  auto wlap = [&](unsigned long long& acc) {
+    if (full_stats) {
+      const unsigned long long now = __builtin_readcyclecounter();
+      acc += now - wt;
+      wt = now;
+    }
+  };
   for (;;) {
     // (1) idle lanes take queued rays
     {
       const unsigned long long m_idle = __ballot(w_slot == SLOT_IDLE);
       const uint32_t n_idle = static_cast<uint32_t>(__popcll(m_idle));
       if (n_idle >= A.pool_refill || n_idle == 64u) {
-        const int32_t aw = static_cast<int32_t>(cu_uni(static_cast<uint32_t>(lds_load(&G->avail_w))));
+        const int32_t aw = static_cast<int32_t>(cu_uni(static_cast<uint32_t>(lds_load(&G->avail[CQ_WALK]))));
         if (aw > 0) {
           const uint32_t want = n_idle < static_cast<uint32_t>(aw) ? n_idle : static_cast<uint32_t>(aw);
           uint32_t e = 0;
-          const uint32_t got = pop(CQ_WALK, ring_w, true, want, m_idle, e);
+          const uint32_t got = pop(CQ_WALK, want, m_idle, e);
+          d_ref += stat_inc, d_refr += full_stats ? got : 0u;
           if (w_slot == SLOT_IDLE && lane_rank(m_idle, lane) < got) {
+            if (full_stats) {
+              __hip_atomic_fetch_add(&wrec->wait_cyc[4], static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_readcyclecounter()) - tq[e & 0x7fffu]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __hip_atomic_fetch_add(&wrec->wait_n[4], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             w_slot = e & 0x7fffu;
             w_type = (e & CU_RAY_S) ? 0u : 1u;
             w_setup = true;
@@ -743,6 +773,7 @@ VD void cu_walk(uint32_t& n_closest, uint32_t& n_shadow) {
         w_setup = false;
       }
     }
+    wlap(wc0);
     if (__ballot(w_slot != SLOT_IDLE) == 0ull) break;
 
     // (3) walk until pool_refill rays have finished (or nothing is left to walk): "while-while",
@@ -753,6 +784,7 @@ VD void cu_walk(uint32_t& n_closest, uint32_t& n_shadow) {
         for (;;) {
           const bool act = cur != REF_DONE && ref_count(cur) == 0;
           if (!__any(act)) break;
+          if (full_stats) d_box += 1u, d_boxl += static_cast<uint32_t>(__popcll(__ballot(act)));
           if (act) {
             v4f na, nb, nc;
             v2u refs;
@@ -801,7 +833,9 @@ VD void cu_walk(uint32_t& n_closest, uint32_t& n_shadow) {
         box_loop(std::true_type{});
       else
         box_loop(std::false_type{});
+      wlap(wc1);
 
+      if (full_stats) d_leaf += 1u, d_leafl += static_cast<uint32_t>(__popcll(__ballot(cur != REF_DONE && (!DEEP || ref_count(cur) != 0))));
       if (cur != REF_DONE && (!DEEP || ref_count(cur) != 0)) {
         const uint32_t first = ref_index(cur), count = ref_count(cur);
         c_leaf += stat_inc;
@@ -846,6 +880,7 @@ VD void cu_walk(uint32_t& n_closest, uint32_t& n_shadow) {
         cur = (stop || sp == 0) ? REF_DONE : popped;
         sp = sp_below;
       }
+      wlap(wc2);
       const uint32_t n_fin = static_cast<uint32_t>(__popcll(__ballot(w_slot != SLOT_IDLE && cur == REF_DONE)));
       const uint32_t n_act = static_cast<uint32_t>(__popcll(__ballot(w_slot != SLOT_IDLE && cur != REF_DONE)));
       if (n_act == 0 || n_fin >= A.pool_refill) break;
@@ -897,7 +932,8 @@ VD void cu_walk(uint32_t& n_closest, uint32_t& n_shadow) {
           if (complete) {
             const uint32_t t = cls == 0 ? t0 : (cls == 1 ? t1 : (cls == 2 ? t2 : t3));
             const unsigned long long m = cls == 0 ? m0 : (cls == 1 ? m1 : (cls == 2 ? m2 : m3));
-            ring_v[cls * P + mod_v(t + lane_rank(m, lane))] = static_cast<uint16_t>(w_slot);
+            *ring_at(cls, t + lane_rank(m, lane)) = static_cast<uint16_t>(w_slot);
+            if (full_stats) tq[w_slot] = static_cast<uint32_t>(__builtin_readcyclecounter());
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           if (lane < 4u && n_me != 0u) lds_add_rtn(&G->avail[lane], static_cast<int32_t>(n_me));
@@ -905,13 +941,19 @@ VD void cu_walk(uint32_t& n_closest, uint32_t& n_shadow) {
         if (done) w_slot = SLOT_IDLE;
       }
     }
+    wlap(wc3);
     if (cu_uni(lds_load(&G->abort)) != 0u) break;
   }
   if (full_stats) {
+    if (lane == 0) wrec->w_cyc[0] += wc0, wrec->w_cyc[1] += wc1, wrec->w_cyc[2] += wc2, wrec->w_cyc[3] += wc3;
     __hip_atomic_fetch_add(&wrec->internal, c_internal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __hip_atomic_fetch_add(&wrec->leaf, c_leaf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __hip_atomic_fetch_add(&wrec->prim, c_prim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __hip_atomic_fetch_add(&wrec->sphere, c_sphere, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) {
+      wrec->box_pass += d_box, wrec->box_lanes += d_boxl, wrec->leaf_round += d_leaf, wrec->leaf_lanes += d_leafl;
+      wrec->sessions += 1, wrec->refills += d_ref, wrec->refill_rays += d_refr;
+    }
   }
 }
 
@@ -924,7 +966,7 @@ render_cu_kernel(const CuKArgs ka) {
     const CuKPtr K = cu_kargs();
     CU_STAGE_LOCALS(K);
     stage_lds(g, A, (VIMG_LDS unsigned char*)lds_raw);
-    if (lane < sizeof(CuWaveRec) / 4u) reinterpret_cast<VIMG_LDS uint32_t*>(wrec)[lane] = 0u;
+    for (uint32_t i = lane; i < sizeof(CuWaveRec) / 4u; i += 64u) reinterpret_cast<VIMG_LDS uint32_t*>(wrec)[i] = 0u;
     for (uint32_t i = threadIdx.x; i < A.lds_leaf * 3u; i += blockDim.x)
       lds_leaf[i] = reinterpret_cast<gptr<v4f>>(g.leaf_prims)[i];
     // every slot starts "fresh" in the finisher queue: it needs a pixel
@@ -933,11 +975,14 @@ render_cu_kernel(const CuKArgs ka) {
       ring_v[s] = static_cast<uint16_t>(s);
       ring_v[P + s] = CU_EMPTY, ring_v[2u * P + s] = CU_EMPTY, ring_v[3u * P + s] = CU_EMPTY;
       ring_w[s] = CU_EMPTY, ring_w[P + s] = CU_EMPTY;
+      tq[s] = static_cast<uint32_t>(__builtin_readcyclecounter());
     }
     if (threadIdx.x == 0) {
-      G->avail[0] = static_cast<int32_t>(P), G->avail[1] = 0, G->avail[2] = 0, G->avail[3] = 0;
-      G->avail_w = 0, G->live = P, G->pixels_left = 1u, G->abort = 0u;
-      for (int k = 0; k < 5; ++k) G->tail[k] = (k == 0) ? P : 0u, G->head[k] = 0u;
+      for (uint32_t q = 0; q < 8u; ++q) G->avail[q] = (q == 0u) ? static_cast<int32_t>(P) : 0;
+      G->live = P, G->pixels_left = 1u, G->abort = 0u;
+      for (uint32_t q = 0; q < CQ_COUNT; ++q) G->tail[q] = (q == 0u) ? P : 0u, G->head[q] = 0u;
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      G->t0_lo = static_cast<uint32_t>(t0), G->t0_hi = static_cast<uint32_t>(t0 >> 32);
     }
     __syncthreads();
   }
@@ -961,14 +1006,23 @@ render_cu_kernel(const CuKArgs ka) {
     const v4u av4 = *reinterpret_cast<VIMG_LDS v4u*>(&G->avail[0]);
     const int32_t a0 = skip_fin ? 0 : static_cast<int32_t>(cu_uni(av4.x)), a1 = static_cast<int32_t>(cu_uni(av4.y)),
                   a2 = static_cast<int32_t>(cu_uni(av4.z)), a3 = static_cast<int32_t>(cu_uni(av4.w));
-    const int32_t aw = static_cast<int32_t>(cu_uni(static_cast<uint32_t>(lds_load(&G->avail_w))));
+    const int32_t aw = static_cast<int32_t>(cu_uni(static_cast<uint32_t>(lds_load(&G->avail[CQ_WALK]))));
     const int32_t m01 = a0 > a1 ? a0 : a1, m23 = a2 > a3 ? a2 : a3, qmax = m01 > m23 ? m01 : m23;
-    if (can_walk && aw > 0) {
+    if (full_stats && lane == 0) {
+      wrec->looks += 1;
+      wrec->q_sum[0] += static_cast<uint32_t>(a0 > 0 ? a0 : 0), wrec->q_sum[1] += static_cast<uint32_t>(a1 > 0 ? a1 : 0);
+      wrec->q_sum[2] += static_cast<uint32_t>(a2 > 0 ? a2 : 0), wrec->q_sum[3] += static_cast<uint32_t>(aw > 0 ? aw : 0);
+    }
+    // rays gather in the waves that already walk (they refill on their own); a wave that holds none
+    // joins when cu_join rays wait, or when fewer have waited through cu_patience of its looks
+    if (can_walk && aw > 0 && (aw >= static_cast<int32_t>(A.cu_join) || polls >= A.cu_patience)) {
       // ---------------------------------------------------------------- WALK
       lap(5);
       skip_fin = false, polls = 0, idle_since = 0;
       if (full_stats) iter_wave++;
+      if (A.cu_flex & 4u) __builtin_amdgcn_s_setprio(1);
       cu_walk<TEX, DEEP, NW>(n_closest, n_shadow);
+      if (A.cu_flex & 4u) __builtin_amdgcn_s_setprio(0);
       lap(4);
       continue;
     }
@@ -984,13 +1038,18 @@ render_cu_kernel(const CuKArgs ka) {
       const uint32_t cls = (a0 == qmax) ? 0u : (a1 == qmax ? 1u : (a2 == qmax ? 2u : 3u));
       const uint32_t want = qmax < 64 ? static_cast<uint32_t>(qmax) : 64u;
       uint32_t e = 0;
-      const uint32_t n = pop(cls, ring_v + cls * P, false, want, ~0ull, e);
+      const uint32_t n = pop(cls, want, ~0ull, e);
       if (n == 0u) continue;   // another wave took them
       lap(5);
       if (full_stats) iter_wave++;
       if (full_stats && lane == 0) wrec->nbatch[cls] += 1, wrec->nslots[cls] += n;
+      if (full_stats && lane < n) {
+        __hip_atomic_fetch_add(&wrec->wait_cyc[cls], static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_readcyclecounter()) - tq[e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&wrec->wait_n[cls], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
       bool all_pending = false;
       const bool by_class = A.pool_classes == 3u;
+      if (A.cu_flex & 2u) __builtin_amdgcn_s_setprio(1);
       if (cls == 0u)
         cu_vertex<TEX, NW, true, -1>(n, e, all_pending, n_nan);
       else if (cls == 1u && by_class)
@@ -999,6 +1058,7 @@ render_cu_kernel(const CuKArgs ka) {
         cu_vertex<TEX, NW, false, int(VIMG_MAT_PRINCIPLED)>(n, e, all_pending, n_nan);
       else
         cu_vertex<TEX, NW, false, -1>(n, e, all_pending, n_nan);
+      if (A.cu_flex & 2u) __builtin_amdgcn_s_setprio(0);
       skip_fin = all_pending;
       if (!all_pending) polls = 0, idle_since = 0;   // (a batch of waiting slots only is not progress: the watchdog keeps its time)
       lap(cls);
@@ -1019,7 +1079,11 @@ render_cu_kernel(const CuKArgs ka) {
         break;
       }
     }
-    __builtin_amdgcn_s_sleep(4);
+    // (s_sleep takes an immediate)
+    if (A.cu_sleep >= 32u) __builtin_amdgcn_s_sleep(32);
+    else if (A.cu_sleep >= 16u) __builtin_amdgcn_s_sleep(16);
+    else if (A.cu_sleep >= 8u) __builtin_amdgcn_s_sleep(8);
+    else __builtin_amdgcn_s_sleep(4);
   }
 
   // ---- flush event counts: one atomic per wave and counter
@@ -1042,6 +1106,13 @@ render_cu_kernel(const CuKArgs ka) {
         for (int k = 0; k < 6; ++k) atomicAdd(&stats->prof[k], wrec->cyc[k]);
         for (int k = 0; k < 4; ++k) atomicAdd(&stats->prof[6 + k], wrec->nbatch[k]), atomicAdd(&stats->prof[11 + k], wrec->nslots[k]);
         atomicAdd(&stats->prof[10], 1ull);
+        const unsigned long long wd[7] = {wrec->box_pass, wrec->box_lanes, wrec->leaf_round, wrec->leaf_lanes, wrec->sessions,
+                                          wrec->refills, wrec->refill_rays};
+        for (int k = 0; k < 7; ++k) atomicAdd(&stats->prof[16 + k], wd[k]);
+        atomicAdd(&stats->prof[23], wrec->looks);
+        for (int k = 0; k < 4; ++k) atomicAdd(&stats->prof[24 + k], wrec->q_sum[k]);
+        for (int k = 0; k < 4; ++k) atomicAdd(&stats->walk_cyc[k], wrec->w_cyc[k]);
+        for (int k = 0; k < 5; ++k) atomicAdd(&stats->wait_cyc[k], wrec->wait_cyc[k]), atomicAdd(&stats->wait_n[k], wrec->wait_n[k]);
       }
     }
   }

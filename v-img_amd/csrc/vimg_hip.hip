@@ -247,7 +247,8 @@ void options_from_env(VimgHipOptions* o) {
       {"VIMG_HIP_POOL4_RAYS", &o->pool4_rays},             {"VIMG_HIP_LDS_STACK", &o->lds_stack},
       {"VIMG_HIP_POOL_GBREAK", &o->pool_gbreak},       {"VIMG_HIP_CU_WAVES", &o->cu_waves},
       {"VIMG_HIP_CU_WALKERS", &o->cu_walkers},         {"VIMG_HIP_CU_FLEX", &o->cu_flex},
-      {"VIMG_HIP_CU_LOWWATER", &o->cu_lowwater},       {"VIMG_HIP_CU_PATIENCE", &o->cu_patience}};
+      {"VIMG_HIP_CU_LOWWATER", &o->cu_lowwater},       {"VIMG_HIP_CU_PATIENCE", &o->cu_patience},
+      {"VIMG_HIP_CU_JOIN", &o->cu_join},               {"VIMG_HIP_CU_SLEEP", &o->cu_sleep}};
   for (auto& v : vars)
     if (const char* e = getenv(v.name)) *v.field = atoi(e);
 }
@@ -356,10 +357,12 @@ LaunchCfg make_launch_cu(const VimgDeviceScene* s, const VimgRenderParams* p, in
   a.stack_ovf = nullptr;
   // walking waves: five of eight by policy (config 2: the walk is 60 % of the wave cycles); when every
   // wave walks, every wave must be allowed to shade too
-  a.cu_walkers = std::min(nw, std::max(1u, opt_or(o.cu_walkers, nw * 5u / 8u)));
-  a.cu_flex = opt_or(o.cu_flex, 1u) | (a.cu_walkers == nw ? 1u : 0u);
+  a.cu_walkers = 0;   // (set below, once the tree's place is known)
+  a.cu_flex = opt_or(o.cu_flex, 1u);   // (bit 1 / 2: shading / walking at wave priority 1)
   a.cu_lowwater = std::max(1u, opt_or(o.cu_lowwater, 64u));
   a.cu_patience = opt_or(o.cu_patience, 4u);
+  a.cu_join = std::max(1u, opt_or(o.cu_join, 1u));
+  a.cu_sleep = std::min(127u, std::max(1u, opt_or(o.cu_sleep, 4u)));
   a.pool_refill = std::max(1u, opt_or(o.pool_refill, 16u));
   a.pool_vbatch = std::min(64u, std::max(1u, opt_or(o.pool_vbatch, 64u)));
   a.pool_boxmin = std::min(64u, opt_or(o.pool_boxmin, 16u));
@@ -368,8 +371,6 @@ LaunchCfg make_launch_cu(const VimgDeviceScene* s, const VimgRenderParams* p, in
   a.pool_gbreak = 0;
   // LDS of the workgroup: the whole CU's (16 waves) or half of it, minus a margin
   const uint32_t share = (160u * 1024u) / (16u / nw) - 1024u;
-  const uint32_t stack_rows = pool4_stack_rows_of(a.stack_entries, a.stack_lds);
-  const uint32_t stack_bytes = a.cu_walkers * stack_rows * 64u * 4u;
   uint32_t node_budget = 4608u;
   if (o.lds_budget_kb != VIMG_OPT_AUTO) node_budget = uint32_t(std::max(1, o.lds_budget_kb)) * 1024u;
   a.lds_nodes = std::min(node_budget / 56u, s->d.num_nodes);
@@ -377,6 +378,14 @@ LaunchCfg make_launch_cu(const VimgDeviceScene* s, const VimgRenderParams* p, in
   // the build with the overflow path and the global node fetch serves both trees beyond the LDS
   // node cache and stacks deeper than their LDS rows
   c.deep = a.lds_nodes < s->d.num_nodes || a.stack_lds < a.stack_entries;
+  // walking waves (profiles/r3_cu/sweeps.txt): trees in LDS 9 of 16 (config 2 at 512 spp: 8 waves 307,
+  // 9: 304, 10: 325, 11: 337 ms), trees in global memory 10 (stand-ins of configs 4 / 5 at 32 spp:
+  // 8 waves 2 650 / 3 436, 10: 2 796 / 4 019, 12: 2 649 / 3 762 Mrays/s); when every wave walks, every
+  // wave must be allowed to shade too
+  a.cu_walkers = std::min(nw, std::max(1u, opt_or(o.cu_walkers, c.deep ? 10u : 9u)));
+  if (a.cu_walkers == nw) a.cu_flex |= 1u;
+  const uint32_t stack_rows = pool4_stack_rows_of(a.stack_entries, a.stack_lds);
+  const uint32_t stack_bytes = a.cu_walkers * stack_rows * 64u * 4u;
   uint32_t leaf_bytes = 0;
   a.lds_leaf = 0;
   if (s->num_leaf_prims * 48u <= 4096u && o.lds_leaf != 0) {
@@ -391,6 +400,12 @@ LaunchCfg make_launch_cu(const VimgDeviceScene* s, const VimgRenderParams* p, in
   // from the first sample to the last)
   const uint32_t groups = s->num_cus * (16u / nw);
   const uint64_t per_group = (items + groups - 1) / groups;
+  // ... and when the pixels are more than the slots but fewer than 2.7 pools' worth (half a frame of
+  // config 2), a pool of pixels / 2.7: the segments of a pixel are handed from slot to slot, and a
+  // slot that draws a segment whose predecessor is still running can only wait - with 1.65
+  // generations of slots per pixel half of config 2 took 253 ms, with 2.7 (1 040 slots) 176, with 3.5 180
+  if (o.pool_slots == VIMG_OPT_AUTO && per_group > slots && per_group * 10u < uint64_t(slots) * 27u)
+    slots = static_cast<uint32_t>(per_group * 10u / 27u);
   slots = static_cast<uint32_t>(std::min<uint64_t>(slots, per_group + 8u));
   slots = std::max(slots & ~7u, 8u);
   a.pool_slots = slots;
@@ -426,7 +441,11 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
                       bool for_render = true, int sched_override = 0, bool lds_stack_all = false) {
   LaunchCfg c{};
   const VimgHipOptions& o = s->opt;
-  if (for_render && !sched_override && o.scheduler == VIMG_SCHED_CU && !s->too_wide) return make_launch_cu(s, p, sx, sy);
+  // Policy (AUTO): the CU-wide scheduler for every launch - whole frames, thin shards, trace_pixel.  The
+  // lane-bound kernel runs when asked for by name and for frames wider than the 16-bit pixel
+  // coordinates of the slot records; the schedulers of rounds 1 and 2 by name, in the development build.
+  if (for_render && !sched_override && (o.scheduler == VIMG_SCHED_CU || o.scheduler == VIMG_OPT_AUTO) && !s->too_wide)
+    return make_launch_cu(s, p, sx, sy);
   const uint64_t items = (sx >= 0) ? 1 : uint64_t(local_tiles(s, p)) * 64u;
   // ---- which scheduler.  Policy (AUTO): the pooled scheduler with its vertex stage as calls
   // (pool4); launches with too few pixels per wave for pools of 64 slots - test images,
@@ -435,7 +454,7 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   int sched = sched_override ? sched_override : (o.scheduler == VIMG_OPT_AUTO ? 0 : o.scheduler);
   const bool by_policy = (sched == 0);
   if (!for_render) sched = VIMG_SCHED_LANE;   // probes and the heatmap only need the LDS layout
-  if (sched == 0) sched = VIMG_SCHED_POOL4;
+  if (sched == 0) sched = VIMG_SCHED_LANE;   // (AUTO comes here only for frames too wide for the slot records)
   c.group = (sched == VIMG_SCHED_POOL4G);
   if (c.group) sched = VIMG_SCHED_POOL4;   // the same launch in everything but the pool's layout and the kernel build
   if (s->too_wide && sched != VIMG_SCHED_LANE) sched = VIMG_SCHED_LANE;        // slots pack pixel coordinates in 16 bits
@@ -729,7 +748,8 @@ int enqueue_render(VimgDeviceScene* s, const VimgRenderParams* p, float* d_out, 
   if (c.args.num_local_tiles == 0 && sx < 0) return VIMG_OK;
   if (int rc = ensure_stage(s, c, st)) return rc;
   if (!s->d_stage_kargs) HIP_TRY(hipMalloc(&s->d_stage_kargs, std::max(sizeof(StageKArgs), sizeof(Pool4KArgs))));
-  HIP_TRY(hipMemsetAsync(s->d_counter, 0, 2 * sizeof(unsigned int), st));
+  // (the work counter only: the error word behind it is sticky until a blocking call or vimg_hip_check reads it)
+  HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(unsigned int), st));
   if (want_stats) HIP_TRY(hipMemsetAsync(s->d_stats, 0, sizeof(DeviceStats), st));
   DeviceStats* stats = want_stats ? s->d_stats : nullptr;
   if (c.lds_bytes > 48u * 1024u)   // very deep trees: ask for the large dynamic-LDS carve-out
@@ -773,6 +793,7 @@ int check_kernel_error(VimgDeviceScene* s) {
   unsigned int stage_err = 0;
   if (s->d_stage_ctl)
     HIP_TRY(hipMemcpy(&stage_err, &static_cast<StageCtl*>(s->d_stage_ctl)->error.v, sizeof(stage_err), hipMemcpyDeviceToHost));
+  if (words[1] != 0) HIP_TRY(hipMemset(s->d_counter + 1, 0, sizeof(unsigned int)));   // read once
   if (words[1] != 0 || stage_err != 0)
     return fail(VIMG_E_DEVICE, "render kernel watchdog: a wave waited for work that never came "
                                "(the frame is incomplete), code " + std::to_string(words[1] | (stage_err << 8)));
@@ -811,6 +832,22 @@ int fetch_stats(VimgDeviceScene* s, const VimgRenderParams* p, VimgRenderStats* 
       std::fprintf(stderr, "[vimg stage] %-18s %14llu cyc %6.2f %%  batches %10llu  slots/batch %7.2f\n", st_names[k],
                    ds.prof[k], 100.0 * double(ds.prof[k]) / double(total ? total : 1), k < 5 ? ds.prof[6 + k] : 0ull,
                    (k < 5 && ds.prof[6 + k]) ? double(ds.prof[11 + k]) / double(ds.prof[6 + k]) : 0.0);
+    if (ds.prof[16])   // render_cu_kernel: passes of the walk loops and the lanes that took part
+      std::fprintf(stderr, "[vimg walk] box passes %llu lanes/pass %.2f   leaf rounds %llu lanes/round %.2f   sessions %llu   refills %llu rays/refill %.2f\n",
+                   ds.prof[16], double(ds.prof[17]) / double(ds.prof[16]), ds.prof[18], double(ds.prof[19]) / double(ds.prof[18] ? ds.prof[18] : 1),
+                   ds.prof[20], ds.prof[21], double(ds.prof[22]) / double(ds.prof[21] ? ds.prof[21] : 1));
+    if (ds.wait_n[4])
+      std::fprintf(stderr, "[vimg wait] mean cycles in a ring before a wave takes the slot: finisher %.0f  lambertian %.0f  principled %.0f  other %.0f  walk %.0f\n",
+                   double(ds.wait_cyc[0]) / double(ds.wait_n[0] ? ds.wait_n[0] : 1), double(ds.wait_cyc[1]) / double(ds.wait_n[1] ? ds.wait_n[1] : 1),
+                   double(ds.wait_cyc[2]) / double(ds.wait_n[2] ? ds.wait_n[2] : 1), double(ds.wait_cyc[3]) / double(ds.wait_n[3] ? ds.wait_n[3] : 1),
+                   double(ds.wait_cyc[4]) / double(ds.wait_n[4]));
+    if (ds.px_done[1])
+      std::fprintf(stderr, "[vimg wait] pixels finished (last sample written) after: mean %.3f ms, latest %.3f ms\n",
+                   double(ds.px_done[0]) / double(ds.px_done[1]) * 1e-5, double(ds.px_done[2]) * 1e-5);
+    if (ds.prof[23])
+      std::fprintf(stderr, "[vimg walk] cycles: refill+setup %llu  box %llu  leaf %llu  hand-over %llu   |  looks %llu  mean ring counts seen: finisher %.1f lambertian %.1f principled %.1f walk %.1f\n",
+                   ds.walk_cyc[0], ds.walk_cyc[1], ds.walk_cyc[2], ds.walk_cyc[3], ds.prof[23], double(ds.prof[24]) / double(ds.prof[23]),
+                   double(ds.prof[25]) / double(ds.prof[23]), double(ds.prof[26]) / double(ds.prof[23]), double(ds.prof[27]) / double(ds.prof[23]));
 #ifdef VIMG_WALK_DIAG
     static const char* wd_names[12] = {"walk: refill+setup cyc", "walk: box loop cyc", "walk: leaf rounds cyc", "walk: retire cyc",
                                        "box trips", "box lanes", "leaf rounds", "leaf lanes", "leaf prim trips",
@@ -1126,9 +1163,10 @@ int vimg_hip_scene_upload_opts(const VimgScene* sc, const VimgHipOptions* opts, 
   options_from_env(&s->opt);
   if (s->opt.scheduler != VIMG_OPT_AUTO && (s->opt.scheduler < VIMG_SCHED_LANE || s->opt.scheduler > VIMG_SCHED_CU))
     return bail(fail(VIMG_E_INVALID, "options: unknown scheduler"));
-  if ((s->opt.scheduler == VIMG_SCHED_POOL || s->opt.scheduler == VIMG_SCHED_STAGE) && !vimg_has_dev_schedulers())
-    return bail(fail(VIMG_E_UNSUPPORTED, "options: the schedulers POOL and STAGE are reference implementations of the "
-                                         "development build (make dev), not part of this library"));
+  if (s->opt.scheduler != VIMG_OPT_AUTO && s->opt.scheduler != VIMG_SCHED_LANE && s->opt.scheduler != VIMG_SCHED_CU &&
+      !vimg_has_dev_schedulers())
+    return bail(fail(VIMG_E_UNSUPPORTED, "options: the schedulers POOL, POOL4, POOL4G and STAGE are reference implementations "
+                                         "of the development build (make dev), not part of this library"));
   s->too_wide = (cam.res_x > 65535 || cam.res_y > 65535);   // slots pack pixel coordinates in 16 bits
   hipDeviceProp_t prop{};
   if (hipGetDeviceProperties(&prop, g_device) != hipSuccess) return bail(fail(VIMG_E_DEVICE, "hipGetDeviceProperties failed"));
@@ -1136,6 +1174,7 @@ int vimg_hip_scene_upload_opts(const VimgScene* sc, const VimgHipOptions* opts, 
   if (hipMalloc(reinterpret_cast<void**>(&s->d_stats), sizeof(DeviceStats)) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&s->d_counter), 2 * sizeof(unsigned int)) != hipSuccess)
     return bail(fail(VIMG_E_DEVICE, "hipMalloc of scratch failed"));
+  if (hipMemset(s->d_counter, 0, 2 * sizeof(unsigned int)) != hipSuccess) return bail(fail(VIMG_E_DEVICE, "hipMemset of scratch failed"));
   *out = s;
   return VIMG_OK;
 }
@@ -1204,6 +1243,11 @@ int vimg_hip_render_async(VimgDeviceScene* s, const VimgRenderParams* p, void* d
   if (!d_out) return fail(VIMG_E_INVALID, "null output pointer");
   hipStream_t st = stream ? static_cast<hipStream_t>(stream) : g_stream;
   return launch_render(s, p, static_cast<float*>(d_out), st, false, false, -1, -1);
+}
+
+int vimg_hip_check(VimgDeviceScene* s) {
+  if (!s) return fail(VIMG_E_INVALID, "null scene");
+  return check_kernel_error(s);
 }
 
 int vimg_hip_render(VimgDeviceScene* s, const VimgRenderParams* p, void* d_out, void* stream,

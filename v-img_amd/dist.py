@@ -62,6 +62,8 @@ def render_sharded(dev_scene, params_fn, rank, world, group=None):
     gathered = torch.empty((world * stride, 3), dtype=torch.float32, device="cuda")
     dist.all_gather_into_tensor(gathered, slab, group=group)
     image = dev_scene.assemble_shards(gathered, world, stride)
+    torch.cuda.synchronize()
+    dev_scene.check()   # (a no-op after the blocking render above; the guard of callers that switch to render_async)
     return image, stats
 
 

@@ -121,6 +121,11 @@ class DeviceScene:
             _check(self._lib.vimg_hip_render_async(self._h, C.byref(params),
                                                    C.c_void_p(out.data_ptr()), sp))
 
+    def check(self):
+        """After render_async and a synchronisation of its stream: raises HipError when a launch of this
+        scene gave its frame up (the kernel's watchdog), before the frame is used, gathered or timed."""
+        _check(self._lib.vimg_hip_check(self._h))
+
     def render_to_host(self, params, stats=True):
         """Render and copy the framebuffer to a numpy array [H, W, 3] (no torch needed)."""
         w, h = self.resolution
