@@ -76,15 +76,95 @@ def cpu_share():
     return n
 
 
-def measured_traffic(workload):
-    """HBM bytes per launch from the committed rocprofv3 PMC pass of this same workload."""
+def library_fingerprint(path=None):
+    """sha256 of the HIP library in use: what a committed PMC pass is tied to (a kernel or policy
+    change makes a new library, and the counts of the old one must not be divided by the new time)."""
+    import hashlib
+    if path is None:
+        path = os.environ.get("VIMG_HIP_LIB") or os.path.join(ROOT, "v-img_amd", "lib", "libvimg_hip.so")
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        if t.get("workload") == workload:
-            return int(t["hbm_bytes_per_launch"])
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+        h = hashlib.sha256()
+        with open(path, "rb") as f:
+            for chunk in iter(lambda: f.read(1 << 20), b""):
+                h.update(chunk)
+        return h.hexdigest()
+    except OSError:
+        return None
+
+
+def load_pmc_profile(name, workload, kernel, lib_sha256, profiles_dir=None):
+    """One of the two committed PMC summaries (profiles/valu.json, profiles/traffic.json) - but only
+    when it was taken on THIS workload, THIS kernel and THIS build of the library.  Returns
+    (profile or None, "fresh" | "stale: <why>" | "absent")."""
+    path = os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), name)
+    try:
+        t = json.load(open(path))
+    except (OSError, ValueError):
+        return None, "absent"
+    for key, want in (("workload", workload), ("kernel_name", kernel), ("library_sha256", lib_sha256)):
+        if t.get(key) != want:
+            return None, f"stale: {key} of profiles/{name} is {str(t.get(key))[:48]!r}, this run has {str(want)[:48]!r}"
+    return t, "fresh"
+
+
+def build_roofline(kernel_ms, local_bytes, local_rays, kernel_name, workload, lib_sha256, profiles_dir=None):
+    """The `roofline` object of the JSON line for one rank's launch.  The scene of the headline
+    workload (5.8 KB) is served from LDS, so the bound is vector issue, not HBM
+    (MI355X_MICROARCH.md:54,473: a wave64 VALU instruction takes 2 cycles on a SIMD-32, 1024 SIMDs
+    x 2.4 GHz / 2 = 1.2288e12 wave instructions/s = 7.86e13 lane-ops/s).  The instruction counts are
+    a property of the deterministic workload and come from the committed PMC pass - divided by the
+    time measured live, and only when that pass belongs to this kernel and this library ("pmc":
+    "fresh"); otherwise the line falls back to the labelled algorithmic-bytes figure and says why.
+    A shard (N > 1) executes the frame's instructions per ray: the counts scale with its rays."""
+    achieved = local_bytes / (kernel_ms * 1e-3) / 1e9
+    vp, v_state = load_pmc_profile("valu.json", workload, kernel_name, lib_sha256, profiles_dir)
+    tp, t_state = load_pmc_profile("traffic.json", workload, kernel_name, lib_sha256, profiles_dir)
+    roof = {
+        "bound": "valu",
+        "kernel": kernel_name,
+        "pmc": "fresh" if (v_state == t_state == "fresh") else ("absent" if (v_state == t_state == "absent") else "stale"),
+        "hbm": {
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "bytes_per_launch": int(local_bytes),
+            "note": "ALGORITHMIC bytes on the reference layout (SURVEY.md 8d); served by LDS/L1 "
+                    "here, not by HBM - see traffic for the bytes that do cross the L2",
+        },
+        "traffic": None,
+    }
+    if roof["pmc"] != "fresh":
+        roof["pmc_detail"] = {"valu": v_state, "traffic": t_state}
+        vp = tp = None      # both or neither: the two passes describe one build
+    share = 1.0
+    if vp and vp.get("rays_per_launch"):
+        share = local_rays / float(vp["rays_per_launch"])      # a shard's part of the frame's instructions
+    if tp:
+        roof["traffic"] = int(tp["hbm_bytes_per_launch"] * (local_rays / float(tp["rays_per_launch"]) if tp.get("rays_per_launch") else 1.0))
+    if vp:
+        wave_insts = vp["valu_wave_insts_per_launch"] * share
+        wave_rate = wave_insts / (kernel_ms * 1e-3)
+        lane_rate = wave_rate * 64.0 * vp["valu_lane_utilization"]
+        roof.update({
+            "achieved": round(lane_rate / 1e12, 3), "peak": round(VALU_LANE_PEAK / 1e12, 2),
+            "unit": "Tlane-op/s", "frac": round(lane_rate / VALU_LANE_PEAK, 4),
+            "valu": {
+                "wave_insts_per_launch": wave_insts,
+                "wave_insts_per_s": round(wave_rate, 0),
+                "issue_peak_per_s": VALU_ISSUE_PEAK,
+                "issue_frac": round(wave_rate / VALU_ISSUE_PEAK, 4),
+                "lane_utilization": vp["valu_lane_utilization"],
+                "share_of_profiled_launch": round(share, 5),
+                "source": vp.get("source", "profiles/valu.json"),
+            },
+        })
+        if roof["traffic"]:
+            roof["measured_hbm_frac"] = round(roof["traffic"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    else:
+        roof.update({"bound": "valu (unquantified: no fresh PMC pass)",
+                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5),
+                     "note": "no PMC pass of this workload, kernel and library committed: algorithmic-bytes "
+                             "equivalent against the HBM peak, not measured HBM and not the binding roof"})
+    return roof
 
 
 def cpu_baseline(spp):
@@ -149,19 +229,6 @@ def self_launch(args):
         print(line, flush=True)
     if proc.returncode != 0 or line is None:
         raise SystemExit(proc.returncode or 1)
-
-
-def valu_profile(workload):
-    """VALU instruction counts per launch from the committed rocprofv3 PMC pass of this workload
-    (the counts are a property of the deterministic workload; the TIME they are divided by is
-    measured live)."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "valu.json")))
-        if t.get("workload") == workload:
-            return t
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
 
 
 def main():
@@ -275,7 +342,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return {"scene": scene, "dev": dev, "params": params, "frame": frame, "res": res,
                 "elapsed": float(t[0]), "kernel_ms": kernel_ms, "kernel_ms_max": float(t[1]),
-                "rays": float(counts[0]), "paths": float(counts[1]), "local_bytes": local_bytes,
+                "rays": float(counts[0]), "paths": float(counts[1]), "local_bytes": local_bytes, "local_rays": int(st.rays),
                 "kernel": dev.kernel_for(params)}
 
     m = measure(res, args.steps, args.warmup)
@@ -283,6 +350,7 @@ def main():
     W, H = res
     elapsed, kernel_ms, kernel_ms_max = m["elapsed"], m["kernel_ms"], m["kernel_ms_max"]
     total_rays, total_paths, local_bytes, kernel_name = m["rays"], m["paths"], m["local_bytes"], m["kernel"]
+    local_rays = m["local_rays"]
 
     # untimed extra on rank 0 (strong scaling): the whole frame alone, for T1 and --verify
     t1_ms = None
@@ -348,44 +416,7 @@ def main():
             out["t1_ms"] = round(t1_ms, 3)
             out["efficiency"] = round(t1_ms / (n * ms_per_step), 4)
             out["efficiency_kernels_only"] = round(t1_ms / (n * kernel_ms_max), 4)
-        # The roofline the kernel is under.  The scene of this workload (5.8 KB) is served from LDS,
-        # so the bound is vector issue, not HBM: MI355X_MICROARCH.md:54,473 - a wave64 VALU
-        # instruction takes 2 cycles on a SIMD-32, 1024 SIMDs x 2.4 GHz / 2 = 1.2288e12 wave
-        # instructions/s = 7.86e13 lane-ops/s (the 157.3 TFLOPS FP32 vector figure counts an FMA as 2).
-        vp = valu_profile(workload) if n == 1 else None
-        roof = {
-            "bound": "valu",
-            "kernel": kernel_name,
-            "hbm": {
-                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "bytes_per_launch": int(local_bytes),
-                "note": "ALGORITHMIC bytes on the reference layout (SURVEY.md 8d); served by LDS/L1 "
-                        "here, not by HBM - see traffic for the bytes that do cross the L2",
-            },
-            "traffic": measured_traffic(workload) if n == 1 else None,
-        }
-        if vp:
-            wave_rate = vp["valu_wave_insts_per_launch"] / (kernel_ms * 1e-3)
-            lane_rate = wave_rate * 64.0 * vp["valu_lane_utilization"]
-            roof.update({
-                "achieved": round(lane_rate / 1e12, 3), "peak": round(VALU_LANE_PEAK / 1e12, 2),
-                "unit": "Tlane-op/s", "frac": round(lane_rate / VALU_LANE_PEAK, 4),
-                "valu": {
-                    "wave_insts_per_launch": vp["valu_wave_insts_per_launch"],
-                    "wave_insts_per_s": round(wave_rate, 0),
-                    "issue_peak_per_s": VALU_ISSUE_PEAK,
-                    "issue_frac": round(wave_rate / VALU_ISSUE_PEAK, 4),
-                    "lane_utilization": vp["valu_lane_utilization"],
-                    "source": vp.get("source", "profiles/valu.json"),
-                },
-            })
-            if roof["traffic"]:
-                roof["measured_hbm_frac"] = round(roof["traffic"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-        else:
-            roof.update({"achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "note": "no PMC pass of this exact workload committed: algorithmic-bytes "
-                                 "equivalent against the HBM peak, not measured HBM"})
+        roof = build_roofline(kernel_ms, local_bytes, local_rays, kernel_name, workload, library_fingerprint())
         out["roofline"] = roof
         if n == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.cpu_spp)

@@ -669,3 +669,42 @@ def test_tonemap_srgb_quantise_and_png(tmp_path):
     assert np.array_equal(np.asarray(Image.open(path)), out)
     with pytest.raises(host.HostError):
         vimg_amd.tonemap_to_rgb8(img, 9)
+
+
+def test_bench_roofline_refuses_a_stale_pmc_pass(tmp_path):
+    """bench.py divides the instruction counts of a committed rocprofv3 PMC pass by the time it
+    measures live.  The pass is only used when it was taken on this workload, this kernel and this
+    build of the library (sha256); anything else flips the line to "pmc": "stale" (with the reason) and to the
+    labelled algorithmic figure; a shard's counts scale with its rays."""
+    import importlib
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    wl, kern, sha = "disney_spheres.json, mis integrator, 512 spp, 1800x800", "render_cu_kernel<false>", "ab" * 32
+    tie = {"workload": wl, "kernel_name": kern, "library_sha256": sha, "rays_per_launch": 4.0e9}
+    (tmp_path / "valu.json").write_text(json.dumps(dict(tie, valu_wave_insts_per_launch=2.0e11, valu_lane_utilization=0.5)))
+    (tmp_path / "traffic.json").write_text(json.dumps(dict(tie, hbm_bytes_per_launch=4.0e11)))
+    fresh = bench.build_roofline(300.0, 2.0e12, 4.0e9, kern, wl, sha, profiles_dir=str(tmp_path))
+    assert fresh["pmc"] == "fresh" and fresh["unit"] == "Tlane-op/s" and fresh["traffic"] == int(4.0e11)
+    want = 2.0e11 / 0.3 * 64 * 0.5 / bench.VALU_LANE_PEAK
+    assert abs(fresh["frac"] - want) < 1e-3 and abs(fresh["valu"]["issue_frac"] - 2.0e11 / 0.3 / bench.VALU_ISSUE_PEAK) < 1e-3
+    # an eighth of the frame: an eighth of the instructions and of the traffic
+    shard = bench.build_roofline(100.0, 2.5e11, 5.0e8, kern, wl, sha, profiles_dir=str(tmp_path))
+    assert shard["pmc"] == "fresh" and abs(shard["valu"]["wave_insts_per_launch"] - 2.5e10) < 1 and shard["traffic"] == int(5.0e10)
+    for other in (dict(lib_sha256="cd" * 32), dict(kernel_name="render_pool4_kernel<false,group>"), dict(workload=wl.replace("512", "64"))):
+        args = dict(kernel_name=kern, workload=wl, lib_sha256=sha)
+        args.update(other)
+        stale = bench.build_roofline(300.0, 2.0e12, 4.0e9, args["kernel_name"], args["workload"], args["lib_sha256"],
+                                     profiles_dir=str(tmp_path))
+        assert stale["pmc"] == "stale" and stale["pmc_detail"]["valu"].startswith("stale: "), stale
+        assert stale["unit"] == "GB/s" and stale["traffic"] is None and "valu" not in stale
+    absent = bench.build_roofline(300.0, 2.0e12, 4.0e9, kern, wl, sha, profiles_dir=str(tmp_path / "none"))
+    assert absent["pmc"] == "absent" and absent["unit"] == "GB/s"
+    # the fingerprint is the sha256 of the file
+    import hashlib
+    f = tmp_path / "lib.so"
+    f.write_bytes(b"code object")
+    assert bench.library_fingerprint(str(f)) == hashlib.sha256(b"code object").hexdigest()
+    assert bench.library_fingerprint(str(tmp_path / "missing.so")) is None

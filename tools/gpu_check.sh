@@ -31,6 +31,7 @@ for step in "$@"; do
       (cd /tmp && timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc4" -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu --spp 512 > "$OUT/pmc4.log" 2>&1)
       rc=$?; [ $rc -eq 0 ] || exit $rc
       (cd /tmp && timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT --output-format csv -d "$OUT/pmc5" -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu --spp 512 > "$OUT/pmc5.log" 2>&1)
-      rc=$?; [ $rc -eq 0 ] || exit $rc ;;
+      rc=$?; [ $rc -eq 0 ] || exit $rc
+      python3 "$R/tools/pmc_summary.py" "$OUT" "$OUT/pmc1.log" > "$OUT/pmc_summary.json" ;;
   esac
 done

@@ -148,6 +148,7 @@ struct DeviceStats {
   unsigned long long prof[28];
   unsigned long long wait_cyc[5], wait_n[5];   // render_cu_kernel, statistics launches: cycles slots waited in the rings (vertex 0-3, walk), and how many
   unsigned long long px_done[3];    // render_cu_kernel, statistics launches: when pixels finished (10 ns ticks since their workgroup started): sum, count, latest
+  unsigned long long px_hops[3];    // ... vertex-stage visits per pixel (whole segments only): sum, largest, and (finish time << 24 | hops) of the last pixel
   unsigned long long walk_cyc[4];   // render_cu_kernel, statistics launches: cycles of the walk sessions in refill + set-up, box loop, leaf rounds, hand-over
 };
 enum : int { PF_TOTAL = 0, PF_V_LOAD, PF_V_LIGHT, PF_V_SAMPLE, PF_V_EVAL, PF_V_FINISH, PF_V_STORE,

@@ -20,6 +20,17 @@
 //    atomic OR on the slot's flag word tells) hands the slot to the vertex queue of its class.
 //  * the pool is the CU's (up to 16 waves share it), so batches are whatever 64 slots the CU has
 //    waiting, and a thin shard's pixels all sit in LDS slots at once.
+// Measured and NOT kept (profiles/r3_cu/experiments.txt; all bit-identical):
+//  * a second, urgent set of rings for slots whose pixel lags behind the pool's mean sample index:
+//    the last pixel of an eighth of config 2 finished no earlier (19.2 against 18.4 ms at 64 spp - it
+//    is bound by the service time of its hops, 9 Principled vertices per sample, not by queueing)
+//    and the full frame paid 7 % for the second set of pops and ballots;
+//  * both rays of a vertex as ONE ring entry walked by one lane (one pop and one hand-over instead of
+//    two, no join) once many rays wait: config 2 323 against 316 ms, its eighth 141 against 122 ms,
+//    stand-ins of configs 4 / 5 2.40 / 3.60 against 2.80 / 4.01 Grays/s - shadow rays queued
+//    together are walked together;
+//  * 12 waves per compute unit at 168 registers: 351 against 311 ms (config 2), 2.5 / 3.2 against
+//    2.8 / 4.0 Grays/s (stand-ins 4 / 5): the fourth wave per SIMD hides more than 40 registers save.
 // Same device functions, same order of operations per path as every other scheduler: bit-identical.
 #pragma once
 #include <type_traits>
@@ -246,6 +257,8 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan)
   bool primary = true, non_specular_bounce = false;
   v4u r_origin{0u, 0u, 0u, 0u}, r_hit{0u, 0u, 0u, 0u}, r_nee{0u, 0u, 0u, 0u};
   v2u r_hx{0u, 0u};
+  uint32_t hops = 0;   // statistics launches: vertex-stage visits of the slot's pixel so far (kept in CR_SHD.w)
+  if (full_stats && have) hops = recw[(CR_SHD * P + slot) * 4u + 3u] + 1u;
   if (have) {
     const v4u r_t = crd(SC_THROUGHPUT, slot), r_r = crd(SC_RESULT, slot);
     v4u r_a{0u, 0u, 0u, 0u};
@@ -541,10 +554,16 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan)
         out[o + 1] = px_col.y;
         out[o + 2] = px_col.z;
         need_pixel = true;
-        if (full_stats) {   // when pixels finish, in 10 ns ticks since the workgroup started: sum, count, latest
+        if (full_stats) {   // when pixels finish, in 10 ns ticks since the workgroup started: sum, count, latest; and their hops
           const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - (static_cast<unsigned long long>(G->t0_lo) | (static_cast<unsigned long long>(G->t0_hi) << 32));
           DeviceStats* __restrict__ stp = K->stats;
-          if (stp) atomicAdd(&stp->px_done[0], dt), atomicAdd(&stp->px_done[1], 1ull), atomicMax(&stp->px_done[2], dt);
+          if (stp) {
+            atomicAdd(&stp->px_done[0], dt), atomicAdd(&stp->px_done[1], 1ull), atomicMax(&stp->px_done[2], dt);
+            // (time << 24 | hops: the maximum is the pixel that finished last, with its hop count)
+            atomicMax(&stp->px_hops[2], (dt << 24) | static_cast<unsigned long long>(hops & 0xffffffu));
+            atomicAdd(&stp->px_hops[0], static_cast<unsigned long long>(hops)), atomicMax(&stp->px_hops[1], static_cast<unsigned long long>(hops));
+          }
+          hops = 0;
         }
       } else if (n_seg > 1u && smp % seg_len == 0u) {
         // end of a segment: the pixel rests in its record until a slot draws its next segment
@@ -654,7 +673,8 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan)
     if (pending) has_s = false, has_r = false, smp = claim;
     wr(CR_ORG, slot, v4u{fu(ray_o.x), fu(ray_o.y), fu(ray_o.z), fu(shadow_max_t)});
     wr(CR_DIR, slot, v4u{fu(ray_d.x), fu(ray_d.y), fu(ray_d.z), nf});
-    if (has_s) wr(CR_SHD, slot, v4u{fu(shadow_d.x), fu(shadow_d.y), fu(shadow_d.z), 0u});
+    if (has_s) wr(CR_SHD, slot, v4u{fu(shadow_d.x), fu(shadow_d.y), fu(shadow_d.z), hops});
+    else if (full_stats) recw[(CR_SHD * P + slot) * 4u + 3u] = hops;
     cwr(SC_THROUGHPUT, slot, v4u{fu(throughput.x), fu(throughput.y), fu(throughput.z), fu(eta_scale)});
     cwr(SC_RESULT, slot, v4u{fu(result.x), fu(result.y), fu(result.z), fu(prev_pdf)});
     if (has_s) cwr(SC_NEE, slot, v4u{fu(nee_contrib.x), fu(nee_contrib.y), fu(nee_contrib.z), 0u});

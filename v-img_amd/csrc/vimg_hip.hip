@@ -844,6 +844,10 @@ int fetch_stats(VimgDeviceScene* s, const VimgRenderParams* p, VimgRenderStats* 
     if (ds.px_done[1])
       std::fprintf(stderr, "[vimg wait] pixels finished (last sample written) after: mean %.3f ms, latest %.3f ms\n",
                    double(ds.px_done[0]) / double(ds.px_done[1]) * 1e-5, double(ds.px_done[2]) * 1e-5);
+    if (ds.px_done[1])
+      std::fprintf(stderr, "[vimg wait] vertex-stage visits per pixel: mean %.1f, most %llu; the pixel that finished last: %llu visits in %.3f ms = %.2f us per visit (walks included)\n",
+                   double(ds.px_hops[0]) / double(ds.px_done[1]), ds.px_hops[1], ds.px_hops[2] & 0xffffffull, double(ds.px_hops[2] >> 24) * 1e-5,
+                   double(ds.px_hops[2] >> 24) * 1e-2 / double((ds.px_hops[2] & 0xffffffull) ? (ds.px_hops[2] & 0xffffffull) : 1));
     if (ds.prof[23])
       std::fprintf(stderr, "[vimg walk] cycles: refill+setup %llu  box %llu  leaf %llu  hand-over %llu   |  looks %llu  mean ring counts seen: finisher %.1f lambertian %.1f principled %.1f walk %.1f\n",
                    ds.walk_cyc[0], ds.walk_cyc[1], ds.walk_cyc[2], ds.walk_cyc[3], ds.prof[23], double(ds.prof[24]) / double(ds.prof[23]),
