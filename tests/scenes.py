@@ -21,6 +21,24 @@ def json_scene(name, res=None, bvh=abi.BVH_SWEEP):
     return vimg_amd.HostScene.from_json_text(json.dumps(d), bvh=bvh)
 
 
+def odyssey_without_monolith(res=None):
+    """The reference's third known-answer scene, scenes/MIS_light_tests/odyssey_mis.json (a depth-1
+    floor under a large QUAD light, the only analytic pin of triangle-light sampling), without its
+    monolith: that surface is the mesh ../../assets/cube.obj, which the reference tree does not hold
+    (README.md:58).  The floor between the glowing wall (x = -12) and the monolith (x >= -1 whatever
+    the cube's vertices within [-1, 1]^3 are) sees the whole wall with or without it, and at depth 1
+    nothing the monolith reflects arrives there: those pixels are a known answer."""
+    import json
+    with open(os.path.join(SCENES, "MIS_light_tests", "odyssey_mis.json")) as f:
+        d = json.load(f)
+    kept = [sf for sf in d["surfaces"] if sf["type"] != "mesh"]
+    assert len(kept) == 2 and len(d["surfaces"]) == 3
+    d["surfaces"] = kept
+    if res is not None:
+        d["camera"]["resolution"] = [int(res[0]), int(res[1])]
+    return vimg_amd.HostScene.from_json_text(json.dumps(d))
+
+
 def _grid_mesh(n, size, height_fn, uv_scale=1.0):
     xs = np.linspace(-size, size, n + 1, dtype=np.float32)
     gx, gz = np.meshgrid(xs, xs, indexing="ij")

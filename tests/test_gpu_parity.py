@@ -36,13 +36,17 @@ def _ulp_diff(a, b):
     return d
 
 
-def _compare_images(gpu, cpu, what, min_exact=0.999, tol=1e-5):
+def _compare_images(gpu, cpu, what, min_exact=0.999, tol=1e-5, k_sigma=6.0):
     """The bar of the module docstring, per pixel: at least `min_exact` of the pixels bit-identical;
     every other pixel either within tol * (largest radiance of the image) of the oracle's value
     (last-bit difference carried through), or - a path re-routed by a last-bit difference in a
-    transcendental - still one of the estimator's values: bounded by the image's own range.  The
-    re-routed ones are counted inside the (1 - min_exact) allowance and the image mean is held to
-    tol as well."""
+    transcendental - still a draw of the same estimator: within k_sigma standard deviations of the
+    oracle's per-pixel estimate, the deviation taken from the oracle image itself (pixels have
+    independent RNG streams, so the spread of the 5x5 neighbourhood around a pixel estimates the spread
+    of its own mean; a twentieth of the image's range is added for neighbourhoods that happen to be
+    flat).  The re-routed ones are counted inside the (1 - min_exact) allowance and the image mean
+    is held to tol as well."""
+    from scipy.ndimage import uniform_filter
     assert gpu.shape == cpu.shape
     exact = (gpu.view(np.uint32) == cpu.view(np.uint32)).all(axis=-1)
     frac = exact.mean()
@@ -51,11 +55,17 @@ def _compare_images(gpu, cpu, what, min_exact=0.999, tol=1e-5):
     diff[np.isnan(gpu) & np.isnan(cpu)] = 0.0
     px_diff = diff.max(axis=-1)
     rerouted = px_diff > tol * scale
+    c = np.nan_to_num(cpu.astype(np.float64), nan=0.0, posinf=scale, neginf=0.0)
+    mean = uniform_filter(c, size=(5, 5, 1), mode="nearest")
+    var = np.maximum(uniform_filter(c * c, size=(5, 5, 1), mode="nearest") - mean * mean, 0.0)
+    sigma = np.sqrt(var).max(axis=-1) * (25.0 / 24.0) ** 0.5
+    bound = k_sigma * sigma + 0.05 * scale
     print(f"{what}: bit-identical pixels {frac * 100:.4f} %, max |diff| {px_diff.max():.3e}, "
-          f"re-routed pixels {int(rerouted.sum())}")
+          f"re-routed pixels {int(rerouted.sum())}"
+          + (f", the largest at {float((px_diff[rerouted] / np.maximum(sigma[rerouted], 1e-30)).max()):.2f} sigma" if rerouted.any() else ""))
     assert frac >= min_exact, f"{what}: only {frac * 100:.3f} % pixels bit-identical"
     assert rerouted.mean() <= 1.0 - min_exact, f"{what}: {int(rerouted.sum())} pixels beyond {tol} of the range"
-    assert np.all(px_diff[rerouted] <= scale), f"{what}: a differing pixel is outside the image's range"
+    assert np.all(px_diff[rerouted] <= bound[rerouted]), f"{what}: a differing pixel is beyond {k_sigma} sigma of the oracle's estimate"
     assert np.isfinite(gpu).all() == np.isfinite(cpu).all()
     assert np.abs(gpu.mean() - cpu.mean()) <= tol * scale + 1e-3 * abs(cpu.mean())
 
@@ -82,6 +92,20 @@ def test_image_matches_oracle_json_scenes(name, res, spp, depth):
     assert gst.paths == cst.paths
     assert abs(gst.rays - cst.rays) <= max(4, 1e-4 * cst.rays)
     assert gst.nan_samples == cst.nan_samples
+
+
+def test_odyssey_quad_light_floor_on_the_gpu():
+    """The reference's quad-light known-answer scene without its (absent) monolith: GPU = oracle bit
+    for bit at the file's own settings, and the GPU image against the reference's picture on the
+    pixels the monolith cannot touch (tests/test_oracle_pins.py:check_against_odyssey_reference)."""
+    from test_oracle_pins import check_against_odyssey_reference
+    s = scenes.odyssey_without_monolith()
+    p = s.default_params()
+    cpu, cst, _ = O.render(s, p)
+    gpu, gst = _dev(s).render_to_host(p)
+    _compare_images(gpu, cpu, "odyssey without monolith")
+    assert gst.paths == cst.paths and abs(gst.rays - cst.rays) <= max(4, 1e-4 * cst.rays)
+    check_against_odyssey_reference(gpu, s, "GPU")
 
 
 def _dev_opts(scene, **opts):

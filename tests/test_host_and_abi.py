@@ -708,3 +708,37 @@ def test_bench_roofline_refuses_a_stale_pmc_pass(tmp_path):
     f.write_bytes(b"code object")
     assert bench.library_fingerprint(str(f)) == hashlib.sha256(b"code object").hexdigest()
     assert bench.library_fingerprint(str(tmp_path / "missing.so")) is None
+
+
+def test_no_called_function_reads_the_kernel_argument_segment():
+    """Guard of a fault that happened once (round 2, gpurun_out/s1/t.log: "Fatal Python error: Aborted" in
+    render_to_host): under code object v5 a non-inlined device function gets no
+    kernel-argument pointer - __builtin_amdgcn_kernarg_segment_ptr() folds to null there and the first
+    scene access faults.  Rules held by the sources: the builtin appears in ONE place (cu_kargs of
+    render_cu_kernel.h); everything that calls cu_kargs is force-inlined into the kernel (VD) or is the
+    kernel; that header defines no __noinline__ function; and the __noinline__ vertex stage of the
+    development build's render_pool4_kernel takes the address of its argument block as (k_lo, k_hi)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "v-img_amd", "csrc")
+    users = {}
+    for name in sorted(os.listdir(csrc)):
+        text = open(os.path.join(csrc, name)).read()
+        code = re.sub(r"//[^\n]*", "", text)
+        if "__builtin_amdgcn_kernarg_segment_ptr" in code:
+            users[name] = code.count("__builtin_amdgcn_kernarg_segment_ptr")
+    assert users == {"render_cu_kernel.h": 1}, users
+    cu = re.sub(r"//[^\n]*", "", open(os.path.join(csrc, "render_cu_kernel.h")).read())
+    assert "__noinline__" not in cu
+    # every function of the header whose body calls cu_kargs() is VD (= __device__ __forceinline__) or __global__
+    heads = [(m.start(), m.group(0)) for m in re.finditer(r"^(?:VD|__global__)[^\n;{]*\n?[^\n;{]*\{", cu, flags=re.M)]
+    for m in re.finditer(r"cu_kargs\(\)", cu):
+        before = [h for h in heads if h[0] < m.start()]
+        assert before, "cu_kargs() outside a function"
+        assert before[-1][1].startswith(("VD", "__global__")), before[-1][1]
+    assert len(list(re.finditer(r"cu_kargs\(\)", cu))) >= 4      # (definition, two stages, the kernel)
+    # the development build's non-inlined callee: block address through registers, never kernel arguments
+    p4 = re.sub(r"//[^\n]*", "", open(os.path.join(csrc, "render_pool4_kernel.h")).read())
+    sigs = re.findall(r"__noinline__\s+\w+\s+(\w+)\s*\(([^)]*)\)", p4)
+    assert sigs and all(args.strip().startswith("uint32_t k_lo, uint32_t k_hi") for _, args in sigs), sigs
+    assert all("DScene" not in args and "RenderArgs" not in args for _, args in sigs)

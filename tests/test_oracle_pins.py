@@ -189,6 +189,68 @@ def test_sphere_light_scenes_analytic_and_reference_png(name, radius, emit, mean
     assert np.abs(ours - ref).mean() < png_tol
 
 
+def odyssey_floor_mask(s):
+    """Pixels of odyssey_mis.json whose value does not depend on the monolith: the camera ray through
+    the pixel centre reaches the floor (y = 0, |z| < 8.5) at -11.5 < x < -1.5 - between the glowing wall
+    at x = -12 and the monolith, which stands at x >= -1 whatever the absent cube.obj's vertices within
+    [-1, 1]^3 are - without passing through the largest box the monolith can fill
+    ([-1, 1] x [-4.5, 13.5] x [-4, 4] after its translate (0, 0.5, 0) and scale (1, 9, 4)).  From there the
+    whole wall is visible with or without the monolith, and at depth 1 nothing it reflects arrives."""
+    w, h = s.resolution
+    ys, xs = np.mgrid[0:h, 0:w]
+    cam = np.stack([xs.ravel() + 0.5, ys.ravel() + 0.5, np.full(w * h, 0.5), np.full(w * h, 0.5)], 1).astype(np.float32)
+    r = O.probe(s, O.PROBE_CAMERA_RAY, cam).astype(np.float64)
+    o, d = r[:, :3], r[:, 3:6]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = -o[:, 1] / d[:, 1]
+        hit = o + d * t[:, None]
+        floor = (d[:, 1] < 0) & (hit[:, 0] > -11.5) & (hit[:, 0] < -1.5) & (np.abs(hit[:, 2]) < 8.5)
+        t0, t1 = (np.array([-1, -4.5, -4.0]) - o) / d, (np.array([1, 13.5, 4.0]) - o) / d
+    tn, tf = np.minimum(t0, t1).max(1), np.maximum(t0, t1).min(1)
+    clear = ~((tn <= tf) & (tf > 0) & (tn < t))
+    mask = np.zeros((h, w), dtype=bool)
+    sel = floor & clear
+    mask[(h - 1 - ys.ravel())[sel], xs.ravel()[sel]] = True     # image row 0 = top
+    return mask
+
+
+def check_against_odyssey_reference(img_linear, s, what):
+    """[REF] scenes/MIS_light_tests/odyssey_mis-ref.png, the reference's own render of its quad-light
+    known-answer scene (depth 1; the picture is itself a 64-spp render, so pixels carry noise and
+    8x8 block means are compared): on the mask above, our render WITHOUT the monolith must be the
+    same picture - the only fixture of the reference that pins triangle-light sampling
+    (src/geometry/triangle.cpp:178-248) and the quad loader."""
+    ref = np.asarray(Image.open(os.path.join(scenes.SCENES, "MIS_light_tests", "odyssey_mis-ref.png"))).astype(np.float32)[..., :3] / 255
+    ours = vimg_amd.tonemap_to_rgb8(img_linear, 0).astype(np.float32) / 255     # clamp + sRGB + 8 bit
+    mask = odyssey_floor_mask(s)
+    h, w = mask.shape
+    assert mask.sum() > 15000                       # the floor between the wall and the monolith
+    B = 8
+    mb = mask.reshape(h // B, B, w // B, B).all(axis=(1, 3))
+    ob = ours.reshape(h // B, B, w // B, B, 3).mean(axis=(1, 3))[mb]
+    rb = ref.reshape(h // B, B, w // B, B, 3).mean(axis=(1, 3))[mb]
+    corr = np.corrcoef(ob.ravel(), rb.ravel())[0, 1]
+    print(f"{what} vs odyssey_mis-ref.png on {int(mb.sum())} blocks: level ratio {ob.mean() / rb.mean():.4f}, "
+          f"correlation {corr:.5f}, mean |diff| {np.abs(ob - rb).mean():.4f}")
+    assert mb.sum() > 200 and rb.min() > 0.02       # lit floor only
+    assert abs(ob.mean() / rb.mean() - 1) < 0.012
+    assert corr > 0.997 and np.abs(ob - rb).mean() < 0.006       # (block means of two 64-spp renders)
+    assert np.abs(ours[mask] - ref[mask]).mean() < 0.04       # per pixel: two independent 64-spp renders of a noisy estimator
+    # the mask matters: behind the monolith the reference's floor is in shadow and ours is not
+    behind = np.zeros_like(mask)
+    behind[h // 2:h - 60, w // 2 + 40:w // 2 + 140] = True
+    assert ours[behind & (ref.sum(-1) > 0)].mean() > 1.3 * ref[behind & (ref.sum(-1) > 0)].mean()
+
+
+def test_odyssey_quad_light_floor_against_the_references_picture():
+    s = scenes.odyssey_without_monolith()
+    p = s.default_params()
+    assert (p.samples, p.depth, p.integrator) == (64, 1, abi.INTEGRATOR_MIS)
+    img, st, _ = O.render(s, p)
+    assert st.nan_samples == 0
+    check_against_odyssey_reference(img, s, "oracle")
+
+
 def test_cornell_box_spheres_mean_radiance():   # [SURVEY] 0.16369 0.14589 0.13198, 7.83 rays/path
     s = scenes.json_scene("cornell_box_spheres.json", res=(400, 400))
     img, st, _ = O.render(s, s.default_params(samples=32))

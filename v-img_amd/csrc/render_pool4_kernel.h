@@ -88,7 +88,10 @@ VD void grp_lock(VIMG_LDS Pool4Group* G, unsigned int* err_word) {
 }
 VD void grp_unlock(VIMG_LDS Pool4Group* G) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(&G->lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  // (a wave whose grp_lock gave up holds no lock: once the group is aborting nobody stores 0 over
+  // another wave's lock; the frame is lost anyway and every loop leaves at its next abort test)
+  if ((threadIdx.x & 63u) == 0u && lds_aload(&G->abort) == 0u)
+    __hip_atomic_store(&G->lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // where the shared tables of a group live behind its slot records (pool = first record, PS slots)
 struct Pool4GLayout {
@@ -857,6 +860,9 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
 #define WD_ADD(acc) ((void)0)
 #endif
   for (;;) {
+    if constexpr (GRP) {
+      if (uni(lds_aload(&G->abort)) != 0u) break;
+    }
     if constexpr (GRP) {   // a look at the group's counters (decisions below are re-made under the lock)
       qw_count = uni(lds_aload(&G->qw_count));
       qv_count0 = uni(lds_aload(&G->qv_count[0])), qv_count1 = uni(lds_aload(&G->qv_count[1]));
@@ -1312,6 +1318,9 @@ render_pool4_kernel(const Pool4KArgs* __restrict__ kargs) {
         if constexpr (GRP) qw_count = uni(lds_aload(&G->qw_count));
 
         WD_ADD(wd_ret);
+        if constexpr (GRP) {
+          if (uni(lds_aload(&G->abort)) != 0u) break;   // the launch has been given up (watchdog): no wave keeps walking
+        }
         // (5) leave when a full vertex batch waits, or when nothing is left to walk
         if (qv_count0 >= A.pool_vbatch || qv_count1 >= A.pool_vbatch || qv_count2 >= A.pool_vbatch ||
             qv_count3 >= A.pool_vbatch) {

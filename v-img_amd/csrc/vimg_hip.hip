@@ -487,7 +487,7 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   a.stack_entries = s->d.max_depth + 2;
   a.stack_lds = a.stack_entries;
   a.stack_ovf = nullptr;
-  // pool4 on trees that do not fit in LDS: the first 12 entries of a lane's stack in LDS, the rest in
+  // pool4 on trees that do not fit in LDS: the first `lds_stack` (AUTO 32) entries of a lane's stack in LDS, the rest in
   // global memory (the LDS goes to path slots instead); `lds_stack_all`: second pass, when the tree
   // turned out to fit (the build without the overflow path)
   if (sched == VIMG_SCHED_POOL4 && !lds_stack_all)
