@@ -186,6 +186,10 @@ def check_schedules_against_lane(s, p, schedules, what, twice=True):
         img, st = d.render_to_host(p)
         assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (what, name, d.kernel)
         assert st.as_dict() == rst.as_dict(), (what, name)
+        # a launch without statistics runs the build without the diagnostics (render_cu_kernel<..., DIAG = false>,
+        # the one frames are timed on): same bits
+        plain = d.render_to_host(p, stats=False)
+        assert np.array_equal(plain.view(np.uint32), ref.view(np.uint32)), (what, name, "launch without statistics")
         if twice:
             again, _ = d.render_to_host(p)            # a second launch on the same records
             assert np.array_equal(img.view(np.uint32), again.view(np.uint32)), (what, name)

@@ -23,6 +23,10 @@ for name, res, spp, extra in cases:
         same = bool((img.view(np.uint32) == ref.view(np.uint32)).all())
         print(f"{name} {res} {spp} spp {extra} rep {rep}: {d.kernel_for(p)} same bits {same}, rays {st.rays} vs {rst.rays}", flush=True)
         ok &= same and st.rays == rst.rays
+    plain = d.render_to_host(p, stats=False)      # the build without diagnostics
+    same_plain = bool((plain.view(np.uint32) == ref.view(np.uint32)).all())
+    print("  launch without statistics: same bits", same_plain, flush=True)
+    ok &= same_plain
     px = d.trace_pixel(p, res[0] // 2, res[1] // 2)
     tp_same = bool((np.asarray(px, dtype=np.float32).view(np.uint32) == ref[res[1] - 1 - res[1] // 2, res[0] // 2].view(np.uint32)).all())
     print("  trace_pixel same bits", tp_same, flush=True)

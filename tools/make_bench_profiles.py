@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """From the PMC passes of tools/gpu_check.sh (bench.py --steps 1 --warmup 0 --spp 512: one stats
-launch + one timed launch, so every counter is summed over TWO launches of the frame) to the two
+launch, which runs the scheduler's DIAG build and is left out, + one timed launch) to the two
 small files bench.py reads: profiles/valu.json (VALU wave instructions and lane utilisation per
 launch) and profiles/traffic.json (HBM-side bytes per launch: FETCH_SIZE x 2 - the gfx950
 correction of MI355X_MICROARCH.md "HBM" - + WRITE_SIZE, both in KiB units of rocprofv3).
@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 s = json.load(open(os.path.join(src, "pmc_summary.json")))
 line = json.loads([l for l in open(line_file) if l.startswith("{")][-1])
 k = s["counters"]
-launches = 2
+launches = s["launches_per_pass"]
 workload = line["config"]["workload"]
 kernel_name = line["roofline"]["kernel"]
 assert kernel_name.split("<")[0] in s["dispatch"]["Kernel_Name"], (kernel_name, s["dispatch"]["Kernel_Name"])
@@ -24,7 +24,7 @@ rays = round(line["value"] * 1e6 * line["ms_per_step"] * 1e-3)
 ms = None
 for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv")):
     for r in csv.DictReader(open(f)):
-        if kernel_name.split("<")[0] in r["Name"]:
+        if kernel_name.split("<")[0] in r["Name"] and ("render_cu_kernel" not in r["Name"] or ", false>(" in r["Name"]):
             ms = float(r["AverageNs"]) * 1e-6
 tie = {"workload": workload, "kernel_name": kernel_name, "library_sha256": bench.library_fingerprint(),
        "spp": line["config"]["spp"], "rays_per_launch": rays, "ms_per_launch_under_rocprof": ms,

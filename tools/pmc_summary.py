@@ -15,9 +15,17 @@ agg = collections.OrderedDict()
 rows = collections.Counter()
 meta = {}
 KERNELS = ("render_kernel", "render_pool_kernel", "render_pool4_kernel", "render_stage_kernel", "render_cu_kernel")
+def wanted(name):
+    # the CU scheduler has a build for statistics launches (<..., true>) beside the one frames are timed on
+    # (<..., false>): a profile is of the timed one
+    if "render_cu_kernel" in name:
+        return ", false>(" in name
+    return any(n in name for n in KERNELS)
+
+
 for f in sorted(glob.glob(f"{out_dir}/pmc*/*/*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if any(n in r["Kernel_Name"] for n in KERNELS):
+        if wanted(r["Kernel_Name"]):
             agg[r["Counter_Name"]] = agg.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
             rows[(r["Counter_Name"], r["Dispatch_Id"])] += 1
             meta = {k: r[k] for k in ["Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size",

@@ -132,7 +132,7 @@ VD CuKPtr cu_kargs() {
   [[maybe_unused]] float* __restrict__ out = (K)->out;                                                                  \
   [[maybe_unused]] unsigned int* __restrict__ work_counter = (K)->work_counter;                                         \
   [[maybe_unused]] const uint32_t lane = threadIdx.x & 63, wave = cu_uni(threadIdx.x >> 6);                             \
-  [[maybe_unused]] const bool full_stats = A.full_stats != 0;                                                           \
+  [[maybe_unused]] const bool full_stats = DIAG && A.full_stats != 0;   /* (the DIAG build serves statistics launches) */ \
   [[maybe_unused]] const uint32_t stat_inc = full_stats ? 1u : 0u;                                                      \
   [[maybe_unused]] const uint32_t W = static_cast<uint32_t>(g.res_x), H = static_cast<uint32_t>(g.res_y);               \
   [[maybe_unused]] const bool single = A.single_x >= 0;                                                                 \
@@ -237,12 +237,23 @@ VD CuKPtr cu_kargs() {
 // ======================================================================== one vertex batch
 // (the body is render_pool4_kernel's vertex stage; FIN: the finisher queue, MTC: material the shading
 // is specialised for, -1 = any).  `n` slots; lane i < n holds its slot id in `slot`.
-template <bool TEX, int NW, bool FIN, int MTC>
+template <bool TEX, int NW, bool DIAG, bool FIN, int MTC>
 VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan) {
   const CuKPtr K = cu_kargs();
   CU_STAGE_LOCALS(K);
   constexpr bool finisher_batch = FIN;
-  const bool on = lane < n;
+  // A batch of at most 32 slots of a material whose two BSDF evaluations are worth it runs SPLIT: lanes
+  // 32-63 shadow lanes 0-31 (same slot, same loads, same draws, same arithmetic) up to the two
+  // evaluations of a vertex - towards the light and along the sampled direction, independent of each
+  // other - of which each half of the wave then does ONE, in the same instructions; the owner lane takes
+  // the other result from its mirror lane.  A wave that has its SIMD to itself issues one instruction per
+  // four cycles however few lanes are on, so on a frame short of pixels (where the last pixels' chains
+  // of Principled vertices are the frame time) this takes a fifth off the longest stage.
+  constexpr bool CAN_SPLIT = !FIN && MTC != int(VIMG_MAT_LAMBERTIAN);
+  const bool split = CAN_SPLIT && n <= 32u && !(A.cu_flex & 16u);
+  const bool mirror = split && lane >= 32u;
+  if (split) slot = static_cast<uint32_t>(__shfl(static_cast<int>(slot), static_cast<int>(lane & 31u)));
+  const bool on = (split ? (lane & 31u) : lane) < n;
   if (!on) slot = 0u;
   const v4u r_ray = on ? rd(CR_DIR, slot) : v4u{0u, 0u, 0u, 0u};
   uint32_t flags = r_ray.w;
@@ -484,32 +495,42 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan)
       // both BSDF evaluations happen before either ray is traced: the evaluation towards the
       // light is pure, so doing it for a light that turns out occluded changes nothing; its
       // regularisation flag is the one from BEFORE this bounce
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const bool run = (k == 0) ? nee : sc.valid;
+      f3 f_l{0.f, 0.f, 0.f}, f_s{0.f, 0.f, 0.f};   // towards the light / along the sampled direction
+      float pdf_l = 0.f, pdf_s = 0.f;
+#pragma unroll 1
+      for (int pass = 0; pass < (split ? 1 : 2); ++pass) {
+        const bool second = split ? mirror : (pass == 1);   // which of the two this lane evaluates in this pass
+        const bool run = second ? sc.valid : nee;
+        f3 f{0.f, 0.f, 0.f};
+        float pdf = 0.f;
         if (run) {
-          f3 f{0.f, 0.f, 0.f};
-          float pdf = 0.f;
-          const f3 wo = (k == 0) ? li.wi : sc.wo;
-          const RayCone c = (k == 0) ? nee_cone : cone;
-          const bool reg = (k == 0) ? reg_before : non_specular_bounce;
+          const f3 wo = second ? sc.wo : li.wi;
+          const RayCone c = second ? cone : nee_cone;
+          const bool reg = second ? non_specular_bounce : reg_before;
           eval_pdf_pair<TEX, MT>(g, hit, ray_d, wo, c, reg, f, pdf);
-          if (k == 0) {
-            if (pdf != 0 && !is_nan(pdf)) {
-              float Gt = li.G;
-              float mis_weight = balance_heuristic(li.pdf, pdf * Gt);
-              nee_contrib = throughput * f * mis_weight * Gt * light_col / li.pdf;
-            }
-            // pdf == 0 / NaN: nothing is added, but the reference has traced its shadow ray by
-            // then (mis_integrator.cpp:64): it is still traced and counted
-          } else {
-            if (is_nan(pdf)) {
-              sc.valid = false;   // NaN pdf terminates the path (mis_integrator.cpp:108-114)
-            } else {
-              throughput = throughput * (f / pdf);
-              prev_pdf = pdf;
-            }
-          }
+        }
+        if (second) f_s = f, pdf_s = pdf;
+        else f_l = f, pdf_l = pdf;
+      }
+      if (split) {   // the owner lane takes the sampled direction's evaluation from its mirror lane
+        const float sx = __shfl_xor(f_s.x, 32), sy = __shfl_xor(f_s.y, 32), sz = __shfl_xor(f_s.z, 32), sp = __shfl_xor(pdf_s, 32);
+        if (!mirror) f_s = f3{sx, sy, sz}, pdf_s = sp;
+      }
+      if (nee) {
+        if (pdf_l != 0 && !is_nan(pdf_l)) {
+          float Gt = li.G;
+          float mis_weight = balance_heuristic(li.pdf, pdf_l * Gt);
+          nee_contrib = throughput * f_l * mis_weight * Gt * light_col / li.pdf;
+        }
+        // pdf == 0 / NaN: nothing is added, but the reference has traced its shadow ray by
+        // then (mis_integrator.cpp:64): it is still traced and counted
+      }
+      if (sc.valid) {
+        if (is_nan(pdf_s)) {
+          sc.valid = false;   // NaN pdf terminates the path (mis_integrator.cpp:108-114)
+        } else {
+          throughput = throughput * (f_s / pdf_s);
+          prev_pdf = pdf_s;
         }
       }
       has_s = nee;
@@ -664,7 +685,7 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan)
   }
 
   // ---- registers -> slot state, slot -> walk ring (both rays of the vertex at once) or finisher ring
-  const bool keep = on && !retire;
+  const bool keep = on && !retire && !mirror;
   if (keep) {
     // a slot that waits for its item's previous segment stays "fresh" and keeps the claim
     const uint32_t nf = pending ? (CF_FRESH | CF_PRIMARY)
@@ -712,7 +733,7 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan)
 // ======================================================================== one walk session
 // Refill idle lanes from the walk ring, step the rays, hand finished ones over; ends when the wave
 // holds no ray and the ring is empty.
-template <bool TEX, bool DEEP, int NW>
+template <bool TEX, bool DEEP, int NW, bool DIAG>
 VD void cu_walk(uint32_t& n_closest, uint32_t& n_shadow) {
   const CuKPtr K = cu_kargs();
   CU_STAGE_LOCALS(K);
@@ -979,7 +1000,10 @@ VD void cu_walk(uint32_t& n_closest, uint32_t& n_shadow) {
 
 // NW: waves of the workgroup (16: one workgroup is the whole CU at four waves per SIMD, 128 registers);
 // WPS: waves per SIMD the register budget leaves room for.
-template <bool TEX, bool DEEP, int NW, int WPS>
+// DIAG: the build of statistics launches (full_stats): event counts beyond the two ray counts, cycles by
+// stage, ring occupancy and waiting times, passes and lanes of the walk loops, when pixels finish.  The
+// build without them is what a frame is timed on - as runtime branches they cost it 4 % (304 -> 316 ms).
+template <bool TEX, bool DEEP, int NW, int WPS, bool DIAG>
 __global__ void __launch_bounds__(NW * 64, WPS)
 render_cu_kernel(const CuKArgs ka) {
   {
@@ -1041,7 +1065,7 @@ render_cu_kernel(const CuKArgs ka) {
       skip_fin = false, polls = 0, idle_since = 0;
       if (full_stats) iter_wave++;
       if (A.cu_flex & 4u) __builtin_amdgcn_s_setprio(1);
-      cu_walk<TEX, DEEP, NW>(n_closest, n_shadow);
+      cu_walk<TEX, DEEP, NW, DIAG>(n_closest, n_shadow);
       if (A.cu_flex & 4u) __builtin_amdgcn_s_setprio(0);
       lap(4);
       continue;
@@ -1071,13 +1095,13 @@ render_cu_kernel(const CuKArgs ka) {
       const bool by_class = A.pool_classes == 3u;
       if (A.cu_flex & 2u) __builtin_amdgcn_s_setprio(1);
       if (cls == 0u)
-        cu_vertex<TEX, NW, true, -1>(n, e, all_pending, n_nan);
+        cu_vertex<TEX, NW, DIAG, true, -1>(n, e, all_pending, n_nan);
       else if (cls == 1u && by_class)
-        cu_vertex<TEX, NW, false, int(VIMG_MAT_LAMBERTIAN)>(n, e, all_pending, n_nan);
+        cu_vertex<TEX, NW, DIAG, false, int(VIMG_MAT_LAMBERTIAN)>(n, e, all_pending, n_nan);
       else if (cls == 2u && by_class)
-        cu_vertex<TEX, NW, false, int(VIMG_MAT_PRINCIPLED)>(n, e, all_pending, n_nan);
+        cu_vertex<TEX, NW, DIAG, false, int(VIMG_MAT_PRINCIPLED)>(n, e, all_pending, n_nan);
       else
-        cu_vertex<TEX, NW, false, -1>(n, e, all_pending, n_nan);
+        cu_vertex<TEX, NW, DIAG, false, -1>(n, e, all_pending, n_nan);
       if (A.cu_flex & 2u) __builtin_amdgcn_s_setprio(0);
       skip_fin = all_pending;
       if (!all_pending) polls = 0, idle_since = 0;   // (a batch of waiting slots only is not progress: the watchdog keeps its time)
@@ -1103,7 +1127,8 @@ render_cu_kernel(const CuKArgs ka) {
     if (A.cu_sleep >= 32u) __builtin_amdgcn_s_sleep(32);
     else if (A.cu_sleep >= 16u) __builtin_amdgcn_s_sleep(16);
     else if (A.cu_sleep >= 8u) __builtin_amdgcn_s_sleep(8);
-    else __builtin_amdgcn_s_sleep(4);
+    else if (A.cu_sleep >= 4u) __builtin_amdgcn_s_sleep(4);
+    else __builtin_amdgcn_s_sleep(1);
   }
 
   // ---- flush event counts: one atomic per wave and counter

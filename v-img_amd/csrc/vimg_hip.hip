@@ -295,7 +295,9 @@ StageKernel pick_stage_kernel(const VimgDeviceScene* s, bool deep) { return vimg
 Pool4Kernel pick_pool4_kernel(const VimgDeviceScene* s, bool deep, int wps, bool group) {
   return vimg_pool4_kernel(s->textured, deep, wps, group);
 }
-CuKernel pick_cu_kernel(const VimgDeviceScene* s, bool deep, int nw) { return vimg_cu_kernel(s->textured, deep, nw); }
+CuKernel pick_cu_kernel(const VimgDeviceScene* s, bool deep, int nw, bool diag = false) {
+  return diag ? vimg_cu_kernel_diag(s->textured, deep, nw) : vimg_cu_kernel(s->textured, deep, nw);
+}
 const void* kernel_of(const VimgDeviceScene* s, const LaunchCfg& c) {
   if (c.sched == VIMG_SCHED_CU) return reinterpret_cast<const void*>(pick_cu_kernel(s, c.deep, c.cu_waves));
   if (c.sched == VIMG_SCHED_STAGE) return reinterpret_cast<const void*>(pick_stage_kernel(s, c.deep));
@@ -358,12 +360,12 @@ LaunchCfg make_launch_cu(const VimgDeviceScene* s, const VimgRenderParams* p, in
   // walking waves: five of eight by policy (config 2: the walk is 60 % of the wave cycles); when every
   // wave walks, every wave must be allowed to shade too
   a.cu_walkers = 0;   // (set below, once the tree's place is known)
-  a.cu_flex = opt_or(o.cu_flex, 1u);   // (bit 1 / 2: shading / walking at wave priority 1)
+  a.cu_flex = opt_or(o.cu_flex, 1u);   // (bit 1 / 2: shading / walking at wave priority 1; bit 4: no split batches)
   a.cu_lowwater = std::max(1u, opt_or(o.cu_lowwater, 64u));
   a.cu_patience = opt_or(o.cu_patience, 4u);
   a.cu_join = std::max(1u, opt_or(o.cu_join, 1u));
   a.cu_sleep = std::min(127u, std::max(1u, opt_or(o.cu_sleep, 4u)));
-  a.pool_refill = std::max(1u, opt_or(o.pool_refill, 16u));
+  a.pool_refill = 16u;   // (set below, once the tree's place is known)
   a.pool_vbatch = std::min(64u, std::max(1u, opt_or(o.pool_vbatch, 64u)));
   a.pool_boxmin = std::min(64u, opt_or(o.pool_boxmin, 16u));
   a.pool_starve = std::min(64u, std::max(1u, opt_or(o.pool_starve, 16u)));   // smallest partial batch worth a wave at once
@@ -383,23 +385,38 @@ LaunchCfg make_launch_cu(const VimgDeviceScene* s, const VimgRenderParams* p, in
   // 8 waves 2 650 / 3 436, 10: 2 796 / 4 019, 12: 2 649 / 3 762 Mrays/s); when every wave walks, every
   // wave must be allowed to shade too
   a.cu_walkers = std::min(nw, std::max(1u, opt_or(o.cu_walkers, c.deep ? 10u : 9u)));
-  if (a.cu_walkers == nw) a.cu_flex |= 1u;
+  // finished rays that send a walking wave to its rings (hand-over, then refill): 16 on trees in LDS; on
+  // trees in global memory, where a pass waits for memory and a finished ray would wait with it, 2
+  // (stand-ins of configs 4 / 5: an eighth of the frame at 128 spp 82.8 / 77.9 against 93.3 / 82.3 ms,
+  // a quarter 87.7 against 92.2, a half 101.9 against 107.8, the whole frame unchanged)
+  a.pool_refill = std::max(1u, opt_or(o.pool_refill, c.deep ? 2u : 16u));
   const uint32_t stack_rows = pool4_stack_rows_of(a.stack_entries, a.stack_lds);
-  const uint32_t stack_bytes = a.cu_walkers * stack_rows * 64u * 4u;
   uint32_t leaf_bytes = 0;
   a.lds_leaf = 0;
   if (s->num_leaf_prims * 48u <= 4096u && o.lds_leaf != 0) {
     a.lds_leaf = s->num_leaf_prims;
     leaf_bytes = a.lds_leaf * 48u;
   }
-  const uint32_t fixed = node_bytes + stack_bytes + cu_pool_bytes(0, nw) + leaf_bytes + 64u;
-  uint32_t slots = share > fixed ? (share - fixed) / CU_LDS_BYTES : 0u;
-  slots = std::min(slots, 4096u);
-  if (o.pool_slots != VIMG_OPT_AUTO) slots = std::min(slots, uint32_t(std::max(0, o.pool_slots)));
+  auto slots_with = [&](uint32_t walkers) {
+    const uint32_t fixed = node_bytes + walkers * stack_rows * 256u + cu_pool_bytes(0, nw) + leaf_bytes + 64u;
+    uint32_t n = share > fixed ? (share - fixed) / CU_LDS_BYTES : 0u;
+    n = std::min(n, 4096u);
+    // (trees in LDS: the rate is flat from 1 152 slots on - config 2 at 512 spp: 896 slots 323, 1 024: 305,
+    // 1 152: 297.7, 1 280: 297.7, 1 408: 298.4, all 1 490 the LDS holds: 300.2 ms; smaller cold regions stay in L2)
+    if (!c.deep && o.pool_slots == VIMG_OPT_AUTO) n = std::min(n, 1280u);
+    if (o.pool_slots != VIMG_OPT_AUTO) n = std::min(n, uint32_t(std::max(0, o.pool_slots)));
+    return n;
+  };
   // never more slots than the launch has pixels per workgroup (a thin shard's pixels each own a slot
   // from the first sample to the last)
   const uint32_t groups = s->num_cus * (16u / nw);
   const uint64_t per_group = (items + groups - 1) / groups;
+  // a launch whose pixels all own a slot, on a tree in LDS: every wave walks AND shades (a quarter of
+  // config 2: 135.0 against 142.4 ms; an eighth and a third: no difference)
+  if (o.cu_walkers == VIMG_OPT_AUTO && !c.deep && o.pool_slots == VIMG_OPT_AUTO && per_group + 8u <= slots_with(nw)) a.cu_walkers = nw;
+  if (a.cu_walkers == nw) a.cu_flex |= 1u;
+  const uint32_t stack_bytes = a.cu_walkers * stack_rows * 256u;
+  uint32_t slots = slots_with(a.cu_walkers);
   // ... and when the pixels are more than the slots but fewer than 2.7 pools' worth (half a frame of
   // config 2), a pool of pixels / 2.7: the segments of a pixel are handed from slot to slot, and a
   // slot that draws a segment whose predecessor is still running can only wait - with 1.65
@@ -507,7 +524,7 @@ LaunchCfg make_launch(const VimgDeviceScene* s, const VimgRenderParams* p, int s
   a.lds_nodes = std::min(nodes, s->d.num_nodes);
   c.lds_bytes = ((a.lds_nodes * 56u + 255u) & ~255u) + stack_bytes;
   a.pool_slots = 0;
-  a.pool_refill = std::max(1u, opt_or(o.pool_refill, 16u));
+  a.pool_refill = 16u;   // (set below, once the tree's place is known)
   a.pool_vbatch = std::min(64u, std::max(1u, opt_or(o.pool_vbatch, 64u)));
   // config 4 / 5 stand-ins: never 1.02 / 1.74, 8 lanes 1.19 / 2.10, 16: 1.18 / 2.13, 24: 1.20 / 2.13,
   // 40: 1.15 / 1.93 Grays/s
@@ -752,8 +769,10 @@ int enqueue_render(VimgDeviceScene* s, const VimgRenderParams* p, float* d_out, 
   HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(unsigned int), st));
   if (want_stats) HIP_TRY(hipMemsetAsync(s->d_stats, 0, sizeof(DeviceStats), st));
   DeviceStats* stats = want_stats ? s->d_stats : nullptr;
-  if (c.lds_bytes > 48u * 1024u)   // very deep trees: ask for the large dynamic-LDS carve-out
-    HIP_TRY(hipFuncSetAttribute(kernel_of(s, c), hipFuncAttributeMaxDynamicSharedMemorySize, int(c.lds_bytes)));
+  if (c.lds_bytes > 48u * 1024u) {   // ask for the large dynamic-LDS carve-out
+    const void* kfn = (c.sched == VIMG_SCHED_CU && full_stats) ? reinterpret_cast<const void*>(pick_cu_kernel(s, c.deep, c.cu_waves, true)) : kernel_of(s, c);
+    HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, int(c.lds_bytes)));
+  }
   if (ev0 && c.sched != VIMG_SCHED_STAGE && c.sched != VIMG_SCHED_POOL4) HIP_TRY(hipEventRecord(ev0, st));
   if (c.sched == VIMG_SCHED_STAGE)
   {
@@ -771,7 +790,7 @@ int enqueue_render(VimgDeviceScene* s, const VimgRenderParams* p, float* d_out, 
     hipLaunchKernelGGL(pick_pool4_kernel(s, c.deep, c.wps, c.group), dim3(c.grid), dim3(256), c.lds_bytes, st,
                        static_cast<const Pool4KArgs*>(blk));
   } else if (c.sched == VIMG_SCHED_CU)
-    hipLaunchKernelGGL(pick_cu_kernel(s, c.deep, c.cu_waves), dim3(c.grid), dim3(uint32_t(c.cu_waves) * 64u), c.lds_bytes, st,
+    hipLaunchKernelGGL(pick_cu_kernel(s, c.deep, c.cu_waves, full_stats), dim3(c.grid), dim3(uint32_t(c.cu_waves) * 64u), c.lds_bytes, st,
                        CuKArgs{s->d, c.args, d_out, stats, s->d_counter});
   else
     hipLaunchKernelGGL(pick_kernel(s, c.pooled, c.wps, c.deep), dim3(c.grid), dim3(256), c.lds_bytes, st, s->d, c.args,
