@@ -149,6 +149,8 @@ struct DeviceStats {
   unsigned long long wait_cyc[5], wait_n[5];   // render_cu_kernel, statistics launches: cycles slots waited in the rings (vertex 0-3, walk), and how many
   unsigned long long px_done[3];    // render_cu_kernel, statistics launches: when pixels finished (10 ns ticks since their workgroup started): sum, count, latest
   unsigned long long px_hops[3];    // ... vertex-stage visits per pixel (whole segments only): sum, largest, and (finish time << 24 | hops) of the last pixel
+  unsigned long long ray_cyc[2];    // ... cycles rays spent in a walking lane (pop to hand-over): sum, count
+  unsigned long long pv_cyc[7];     // ... Principled batches: cycles in state loads, hit record + path logic, light sample, BSDF sample, evaluations, stores + hand-over; batches
   unsigned long long walk_cyc[4];   // render_cu_kernel, statistics launches: cycles of the walk sessions in refill + set-up, box loop, leaf rounds, hand-over
 };
 enum : int { PF_TOTAL = 0, PF_V_LOAD, PF_V_LIGHT, PF_V_SAMPLE, PF_V_EVAL, PF_V_FINISH, PF_V_STORE,

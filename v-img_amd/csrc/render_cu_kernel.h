@@ -87,8 +87,10 @@ struct CuWaveRec {
   unsigned long long looks, q_sum[4];   // looks of the main loop and the ring counts they saw (finisher, Lambertian, Principled, walk)
   unsigned long long w_cyc[4];          // cycles of a walk session: refill + set-up, box loop, leaf rounds, hand-over
   unsigned long long wait_cyc[5], wait_n[5];   // cycles slots spent in the rings (vertex 0-3, walk) and how many
+  unsigned long long ray_cyc, ray_n;           // cycles rays spent in a walking lane, from the pop to the hand-over
+  unsigned long long pv_cyc[6], pv_n;          // Principled batches: cycles in state loads, hit record + path logic, light sample, BSDF sample, evaluations, stores + hand-over
 };
-static_assert(sizeof(CuWaveRec) == 344, "CuWaveRec layout");
+static_assert(sizeof(CuWaveRec) == 416, "CuWaveRec layout");
 __host__ __device__ constexpr uint32_t cu_pool_bytes(uint32_t slots, uint32_t waves) {
   return CU_LDS_BYTES * slots + uint32_t(sizeof(CuCtl)) + waves * uint32_t(sizeof(CuWaveRec));
 }
@@ -268,6 +270,17 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan)
   bool primary = true, non_specular_bounce = false;
   v4u r_origin{0u, 0u, 0u, 0u}, r_hit{0u, 0u, 0u, 0u}, r_nee{0u, 0u, 0u, 0u};
   v2u r_hx{0u, 0u};
+  constexpr bool PV = DIAG && MTC == int(VIMG_MAT_PRINCIPLED);   // statistics launches: where a Principled batch's cycles go
+  [[maybe_unused]] unsigned long long pv_t = PV ? __builtin_readcyclecounter() : 0ull;
+  [[maybe_unused]] auto pv_lap = [&](int k) {
+    if constexpr (PV) {
+      if (full_stats) {
+        const unsigned long long now = __builtin_readcyclecounter();
+        if (lane == 0) wrec->pv_cyc[k] += now - pv_t;
+        pv_t = now;
+      }
+    }
+  };
   uint32_t hops = 0;   // statistics launches: vertex-stage visits of the slot's pixel so far (kept in CR_SHD.w)
   if (full_stats && have) hops = recw[(CR_SHD * P + slot) * 4u + 3u] + 1u;
   if (have) {
@@ -299,6 +312,7 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan)
     }
   }
 
+  pv_lap(0);
   bool finish = false, at_vertex = false;
   Hit hit;
   hit.p = f3{0.f, 0.f, 0.f};
@@ -401,6 +415,7 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan)
     }
   }
 
+  pv_lap(1);
   // ---- the next rays of a vertex
   bool has_s = false, has_r = false;
   f3 shadow_d{0.f, 0.f, 1.f}, nee_contrib{0.f, 0.f, 0.f};
@@ -479,9 +494,11 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan)
         lights_sample<TEX>(g, hit.p, rng, light_col, li);
         nee = (li.pdf != 0.f);
       }
+      pv_lap(2);
       const bool reg_before = non_specular_bounce;
       RayCone nee_cone = cone;
       Scatter sc = sample_mat<TEX, MT>(g, hit, ray_d, rng, reg_before);
+      pv_lap(3);
       if constexpr (TEX) nee_cone = propagate_reflect_cone(cone, surface_spread_angle * 2.f, hit_dist);
       if (sc.valid) {
         if (!sc.is_specular) non_specular_bounce = true;
@@ -512,6 +529,7 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan)
         if (second) f_s = f, pdf_s = pdf;
         else f_l = f, pdf_l = pdf;
       }
+      pv_lap(4);
       if (split) {   // the owner lane takes the sampled direction's evaluation from its mirror lane
         const float sx = __shfl_xor(f_s.x, 32), sy = __shfl_xor(f_s.y, 32), sz = __shfl_xor(f_s.z, 32), sp = __shfl_xor(pdf_s, 32);
         if (!mirror) f_s = f3{sx, sy, sz}, pdf_s = sp;
@@ -728,6 +746,10 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan)
     const uint32_t n_retired = static_cast<uint32_t>(__popcll(__ballot(on && retire)));
     if (n_retired && lane == 0) __hip_atomic_fetch_sub(&G->live, n_retired, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
+  pv_lap(5);
+  if constexpr (PV) {
+    if (full_stats && lane == 0) wrec->pv_n += 1;
+  }
 }
 
 // ======================================================================== one walk session
@@ -752,6 +774,7 @@ VD void cu_walk(uint32_t& n_closest, uint32_t& n_shadow) {
   rec.e0 = rec.e1 = rec.e2 = rec.inv_det = 0.f;
   uint32_t c_internal = 0, c_leaf = 0, c_prim = 0, c_sphere = 0;   // per-lane event counts of statistics launches
   uint32_t d_box = 0, d_boxl = 0, d_leaf = 0, d_leafl = 0, d_ref = 0, d_refr = 0;   // wave-uniform: passes and lanes (statistics launches)
+  uint32_t t_in = 0;   // statistics launches: when this lane took its ray
   unsigned long long wt = full_stats ? __builtin_readcyclecounter() : 0ull, wc0 = 0, wc1 = 0, wc2 = 0, wc3 = 0;
   auto wlap = [&](unsigned long long& acc) {
     if (full_stats) {
@@ -777,6 +800,7 @@ VD void cu_walk(uint32_t& n_closest, uint32_t& n_shadow) {
               __hip_atomic_fetch_add(&wrec->wait_cyc[4], static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_readcyclecounter()) - tq[e & 0x7fffu]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
               __hip_atomic_fetch_add(&wrec->wait_n[4], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+            if (full_stats) t_in = static_cast<uint32_t>(__builtin_readcyclecounter());
             w_slot = e & 0x7fffu;
             w_type = (e & CU_RAY_S) ? 0u : 1u;
             w_setup = true;
@@ -979,6 +1003,10 @@ VD void cu_walk(uint32_t& n_closest, uint32_t& n_shadow) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           if (lane < 4u && n_me != 0u) lds_add_rtn(&G->avail[lane], static_cast<int32_t>(n_me));
         }
+        if (full_stats && done) {
+          __hip_atomic_fetch_add(&wrec->ray_cyc, static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_readcyclecounter()) - t_in), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(&wrec->ray_n, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         if (done) w_slot = SLOT_IDLE;
       }
     }
@@ -1158,6 +1186,9 @@ render_cu_kernel(const CuKArgs ka) {
         for (int k = 0; k < 4; ++k) atomicAdd(&stats->prof[24 + k], wrec->q_sum[k]);
         for (int k = 0; k < 4; ++k) atomicAdd(&stats->walk_cyc[k], wrec->w_cyc[k]);
         for (int k = 0; k < 5; ++k) atomicAdd(&stats->wait_cyc[k], wrec->wait_cyc[k]), atomicAdd(&stats->wait_n[k], wrec->wait_n[k]);
+        atomicAdd(&stats->ray_cyc[0], wrec->ray_cyc), atomicAdd(&stats->ray_cyc[1], wrec->ray_n);
+        for (int k = 0; k < 6; ++k) atomicAdd(&stats->pv_cyc[k], wrec->pv_cyc[k]);
+        atomicAdd(&stats->pv_cyc[6], wrec->pv_n);
       }
     }
   }

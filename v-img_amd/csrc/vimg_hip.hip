@@ -860,6 +860,14 @@ int fetch_stats(VimgDeviceScene* s, const VimgRenderParams* p, VimgRenderStats* 
                    double(ds.wait_cyc[0]) / double(ds.wait_n[0] ? ds.wait_n[0] : 1), double(ds.wait_cyc[1]) / double(ds.wait_n[1] ? ds.wait_n[1] : 1),
                    double(ds.wait_cyc[2]) / double(ds.wait_n[2] ? ds.wait_n[2] : 1), double(ds.wait_cyc[3]) / double(ds.wait_n[3] ? ds.wait_n[3] : 1),
                    double(ds.wait_cyc[4]) / double(ds.wait_n[4]));
+    if (ds.ray_cyc[1])
+      std::fprintf(stderr, "[vimg wait] mean cycles of a ray in a walking lane (pop to hand-over) %.0f; of a vertex batch: finisher %.0f lambertian %.0f principled %.0f other %.0f\n",
+                   double(ds.ray_cyc[0]) / double(ds.ray_cyc[1]), double(ds.prof[0]) / double(ds.prof[6] ? ds.prof[6] : 1), double(ds.prof[1]) / double(ds.prof[7] ? ds.prof[7] : 1),
+                   double(ds.prof[2]) / double(ds.prof[8] ? ds.prof[8] : 1), double(ds.prof[3]) / double(ds.prof[9] ? ds.prof[9] : 1));
+    if (ds.pv_cyc[6])
+      std::fprintf(stderr, "[vimg wait] a Principled batch, mean cycles: state loads %.0f  hit record + path logic %.0f  light sample %.0f  BSDF sample %.0f  evaluations %.0f  stores + hand-over %.0f\n",
+                   double(ds.pv_cyc[0]) / double(ds.pv_cyc[6]), double(ds.pv_cyc[1]) / double(ds.pv_cyc[6]), double(ds.pv_cyc[2]) / double(ds.pv_cyc[6]),
+                   double(ds.pv_cyc[3]) / double(ds.pv_cyc[6]), double(ds.pv_cyc[4]) / double(ds.pv_cyc[6]), double(ds.pv_cyc[5]) / double(ds.pv_cyc[6]));
     if (ds.px_done[1])
       std::fprintf(stderr, "[vimg wait] pixels finished (last sample written) after: mean %.3f ms, latest %.3f ms\n",
                    double(ds.px_done[0]) / double(ds.px_done[1]) * 1e-5, double(ds.px_done[2]) * 1e-5);
