@@ -41,11 +41,13 @@ int vimg_hip_device_count(void);
  * the same bits.  The reference has no counterpart (its scheduler is the tile loop of
  * include/integrators.h:57-101); these are the knobs of OUR replacement of that loop, at the
  * boundary instead of in the environment.  (For tools/ only, VIMG_HIP_* environment variables
- * still override single fields at upload: scheduler VIMG_HIP_SCHED=lane|pool|stage|pool4|pool4g, the others
- * as named in vimg_hip.hip:options_from_env.) */
+ * still override single fields at upload: scheduler VIMG_HIP_SCHED=cu|lane (pool|stage|pool4|pool4g in the
+ * development build), the others as named in vimg_hip.hip:options_from_env.) */
 #define VIMG_OPT_AUTO (-1)
 enum {
   VIMG_SCHED_LANE = 1,   /* render_kernel: one path per lane, persistent waves */
+  /* 2-5: the schedulers of rounds 1 and 2, reference implementations that only the development build of the
+   * library contains (make dev, v-img_amd/lib/dev/libvimg_hip.so); the product library answers VIMG_E_UNSUPPORTED */
   VIMG_SCHED_POOL = 2,   /* render_pool_kernel: ~240 path slots per wave in LDS, walk + vertex stages in one wave */
   VIMG_SCHED_STAGE = 3,  /* render_stage_kernel: path state in HBM slots, stages coupled by global queues, 4 waves/SIMD */
   VIMG_SCHED_POOL4 = 4,  /* render_pool4_kernel: the pooled scheduler with the vertex stage as calls */
@@ -54,15 +56,15 @@ enum {
 };
 typedef struct VimgHipOptions {
   uint32_t struct_size;       /* sizeof(VimgHipOptions): lets the library accept older callers */
-  int32_t scheduler;          /* AUTO (vimg_hip.hip:make_launch): POOL4G; LANE for launches of small scenes with fewer than ~96 pixels per wave and for trace_pixel */
+  int32_t scheduler;          /* AUTO (vimg_hip.hip:make_launch_cu): CU for every launch; LANE for frames wider than 65 535 pixels */
   int32_t waves_per_simd;     /* register budget: LANE / POOL 2 or 3 (AUTO: LANE 3 for scenes > 32 MiB else 2; POOL 2), POOL4 / POOL4G 3 or 4 (AUTO: 4 for full frames on trees that fit in LDS, else 3) */
   int32_t lds_budget_kb;      /* LDS per workgroup for BVH top + stacks.  AUTO: 40 (LANE), stacks + 4.5 (POOL / STAGE) */
-  int32_t pool_slots;         /* POOL: path slots per wave.  AUTO: what the CU's LDS holds (<= 256) */
+  int32_t pool_slots;         /* CU: path slots per compute unit.  AUTO: what the CU's LDS holds, <= 1280 on trees in LDS, pixels / 2.7 on launches of 1 to 2.7 pools' worth of pixels, never more than pixels per CU + 8.  (POOL..: per wave, <= 256) */
   int32_t pool_segments;      /* POOL: segments a pixel's samples are cut into.  AUTO: ~56 / pool generations, <= 16 (POOL4G at four waves: ~176 / generations, <= 64) */
-  int32_t pool_refill;        /* POOL / STAGE walk: finished rays that trigger a refill pass.  AUTO 16 */
+  int32_t pool_refill;        /* walk: finished rays of a wave that trigger hand-over and refill.  AUTO 16; CU on trees in global memory 2 */
   int32_t pool_vbatch;        /* POOL: queued slots of one class that start a vertex batch.  AUTO 64 */
   int32_t pool_classes;       /* POOL: vertex queues by material, 1..3.  AUTO 3; per-wave POOL4 on trees beyond LDS: 1 */
-  int32_t pool_starve;        /* POOL: idle walk lanes that force a partial vertex batch.  AUTO 24; POOL4 on trees beyond LDS: 32 */
+  int32_t pool_starve;        /* CU: smallest partial vertex batch a wave takes at once.  AUTO 16.  (POOL..: idle walk lanes that force a partial batch, AUTO 24 / 32) */
   int32_t pool_boxmin;        /* POOL / STAGE, deep trees: leave the box loop below this many descending lanes.  AUTO 16 */
   int32_t lds_leaf;           /* POOL / STAGE: 0 = never copy the leaf records to LDS.  AUTO: when they fit 4 KiB */
   int32_t stage_slots;        /* STAGE: path slots in flight.  AUTO: 2 x resident lanes, <= pixels of the launch */
@@ -72,9 +74,9 @@ typedef struct VimgHipOptions {
   int32_t pool4_rays;         /* reserved (two rays per lane in the walk measured slower; 1 is what runs) */
   int32_t lds_stack;          /* POOL4, trees beyond LDS: entries of a lane's traversal stack kept in LDS, the rest in global memory.  AUTO 32 */
   int32_t pool_gbreak;        /* POOL4G: a wave leaves the walk for a full vertex batch only with this many rays or fewer in its lanes.  AUTO 32 */
-  int32_t cu_waves;           /* CU: waves per workgroup, 8 or 16 (one 16-wave workgroup is a whole compute unit).  AUTO 16 */
-  int32_t cu_walkers;         /* CU: waves of a workgroup that walk (the rest only shade).  AUTO: 5/8 of them */
-  int32_t cu_flex;            /* CU: bit 0: a walking wave that holds no ray may run a vertex batch.  AUTO 1 */
+  int32_t cu_waves;           /* CU: reserved; one 16-wave workgroup is a whole compute unit (12 waves at 168 registers measured slower) */
+  int32_t cu_walkers;         /* CU: waves of the 16 that walk (the rest only shade).  AUTO: 9 on trees in LDS, 10 on trees in global memory, all 16 when every pixel of the launch owns a slot (tree in LDS) */
+  int32_t cu_flex;            /* CU: bit 0: a walking wave that holds no ray may run a vertex batch; bit 4 (16): no split batches (the two BSDF evaluations of a vertex on the two halves of the wave when a batch has <= 32 slots); bits 1, 2: shading / walking at wave priority 1 (measurements).  AUTO 1 */
   int32_t cu_lowwater;        /* CU: partial vertex batches run only while fewer rays than this wait in the walk ring.  AUTO 64 */
   int32_t cu_patience;        /* CU: looks in vain after which a wave takes a partial batch of any size.  AUTO 4 */
   int32_t cu_join;            /* CU: queued rays at which a walking wave that holds no ray starts to walk (fewer: after cu_patience looks).  AUTO 1 */
