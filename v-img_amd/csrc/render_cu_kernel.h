@@ -30,7 +30,10 @@
 //    stand-ins of configs 4 / 5 2.40 / 3.60 against 2.80 / 4.01 Grays/s - shadow rays queued
 //    together are walked together;
 //  * 12 waves per compute unit at 168 registers: 351 against 311 ms (config 2), 2.5 / 3.2 against
-//    2.8 / 4.0 Grays/s (stand-ins 4 / 5): the fourth wave per SIMD hides more than 40 registers save.
+//    2.8 / 4.0 Grays/s (stand-ins 4 / 5): the fourth wave per SIMD hides more than 40 registers save;
+//  * stacks for all sixteen waves (they fit beside 1 280 slots) and shading waves that walk while no
+//    batch waits for them, taking rays only until a full batch does: config 2 297.5 against 296.9 ms
+//    at any threshold of 32 to 512 waiting rays - the shading side has no idle time worth lending.
 // Same device functions, same order of operations per path as every other scheduler: bit-identical.
 #pragma once
 #include <type_traits>
