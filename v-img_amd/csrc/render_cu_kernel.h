@@ -31,6 +31,10 @@
 //    together are walked together;
 //  * 12 waves per compute unit at 168 registers: 351 against 311 ms (config 2), 2.5 / 3.2 against
 //    2.8 / 4.0 Grays/s (stand-ins 4 / 5): the fourth wave per SIMD hides more than 40 registers save;
+//  * two-level node records for trees in global memory (a node's record followed by both children's,
+//    192 B per fetch, a second step without a second round trip): stand-ins of configs 4 / 5 132.6 /
+//    149.8 against 118.6 / 125.2 ms - three lines per lane and step load the CU's L1 path more than
+//    the saved round trips relieve it;
 //  * stacks for all sixteen waves (they fit beside 1 280 slots) and shading waves that walk while no
 //    batch waits for them, taking rays only until a full batch does: config 2 297.5 against 296.9 ms
 //    at any threshold of 32 to 512 waiting rays - the shading side has no idle time worth lending.
