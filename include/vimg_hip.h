@@ -76,7 +76,7 @@ typedef struct VimgHipOptions {
   int32_t pool_gbreak;        /* POOL4G: a wave leaves the walk for a full vertex batch only with this many rays or fewer in its lanes.  AUTO 32 */
   int32_t cu_waves;           /* CU: reserved; one 16-wave workgroup is a whole compute unit (12 waves at 168 registers measured slower) */
   int32_t cu_walkers;         /* CU: waves of the 16 that walk (the rest only shade).  AUTO: 9 on trees in LDS, 10 on trees in global memory, all 16 when every pixel of the launch owns a slot (tree in LDS) */
-  int32_t cu_flex;            /* CU: bit 0: a walking wave that holds no ray may run a vertex batch; bit 4 (16): no split batches (the two BSDF evaluations of a vertex on the two halves of the wave when a batch has <= 32 slots); bits 1, 2: shading / walking at wave priority 1 (measurements).  AUTO 1 */
+  int32_t cu_flex;            /* CU: bit 0: a walking wave that holds no ray may run a vertex batch; bit 4 (16): no split batches (the two BSDF evaluations of a vertex on the two halves of the wave when a batch has <= 32 slots); bit 5 (32): EARLY rays - a vertex stage queues its shadow ray right after the light sample and its path ray right after the BSDF sample and finishes (evaluations, stores) beside their walks; bits 1, 2: shading / walking at wave priority 1 (measurements).  AUTO 1, + 32 on launches of fewer than three pools' worth of pixels and on trees in global memory */
   int32_t cu_lowwater;        /* CU: partial vertex batches run only while fewer rays than this wait in the walk ring.  AUTO 64 */
   int32_t cu_patience;        /* CU: looks in vain after which a wave takes a partial batch of any size.  AUTO 4 */
   int32_t cu_join;            /* CU: queued rays at which a walking wave that holds no ray starts to walk (fewer: after cu_patience looks).  AUTO 1 */

@@ -134,6 +134,11 @@ SCHEDULES = {
     # batches and refills as eager as they get; as patient as they get
     "cu/eager": dict(scheduler="cu", pool_refill=1, pool_starve=1, cu_patience=0, cu_join=1, pool_vbatch=8),
     "cu/patient": dict(scheduler="cu", pool_refill=48, pool_starve=64, cu_patience=64, cu_join=64, cu_sleep=32),
+    # rays queued as soon as they are known (three-way join of shadow ray, path ray and vertex stage) / at the end
+    # of the vertex stage; batches never split over the halves of the wave
+    "cu/early": dict(scheduler="cu", cu_flex=33, pool_segments=2),
+    "cu/late": dict(scheduler="cu", cu_flex=1),
+    "cu/nosplit": dict(scheduler="cu", cu_flex=49),
     # one queue of shading vertices instead of one per material class; two
     "cu/1class": dict(scheduler="cu", pool_classes=1),
     "cu/2class": dict(scheduler="cu", pool_classes=2, pool_segments=2),
@@ -235,7 +240,8 @@ def test_cu_scheduler_on_every_feature(case):
     and event counts."""
     s, kw = FEATURE_CASES[case]()
     p = s.default_params(**kw)
-    pick = ("cu", "cu/5", "cu/few", "cu/tiny", "cu/w16", "cu/w1", "cu/eager", "cu/1class", "cu/stack1", "cu/stack3", "cu/nolds")
+    pick = ("cu", "cu/5", "cu/few", "cu/tiny", "cu/w16", "cu/w1", "cu/eager", "cu/early", "cu/late", "cu/1class", "cu/stack1", "cu/stack3",
+            "cu/nolds")
     check_schedules_against_lane(s, p, {k: SCHEDULES[k] for k in pick}, case, twice=False)
 
 

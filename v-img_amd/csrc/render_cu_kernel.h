@@ -51,6 +51,8 @@ enum : uint32_t {
   CF_PRIMARY = 1u, CF_NONSPEC = 2u, CF_HAS_S = 4u, CF_HAS_R = 8u, CF_OCCLUDED = 16u, CF_FOUND = 32u,
   CF_FRESH = 64u, CF_KIND_SPHERE = 128u, CF_DONE_S = 256u, CF_DONE_R = 512u,
   CF_CLS_SHIFT = 10u,     // two bits: material class of the hit primitive (leaf record)
+  CF_DONE_V = 4096u,      // the vertex stage that queued the rays has written the slot's state
+  CF_KILL_R = 8192u,      // the path ray was queued before the vertex stage found the path ended (NaN pdf): ignore its result
   CF_BOUNCE_SHIFT = 16u   // sixteen bits (Russian roulette ends paths long before)
 };
 // hot records of a slot in LDS, [record][slot]
@@ -206,6 +208,60 @@ VD CuKPtr cu_kargs() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                                                              \
     if (lane == 0) lds_add_rtn(&G->avail[q], static_cast<int32_t>(n_));                                                 \
   };                                                                                                                    \
+  /* A slot is complete when the vertex stage that queued its rays has written its state (DONE_V) and every ray it      \
+     queued has been walked; `nw` is the flag word after the caller's own OR.  */                                       \
+  [[maybe_unused]] auto slot_complete = [&](uint32_t nw) -> bool {                                                      \
+    return (nw & CF_DONE_V) && (!(nw & CF_HAS_S) || (nw & CF_DONE_S)) && (!(nw & CF_HAS_R) || (nw & CF_DONE_R));        \
+  };                                                                                                                    \
+  /* the lanes whose OR completed their slot hand it to the vertex ring of its class: 0 = its path ends (miss, no path  \
+     ray, emitter hit under mis, any hit under the normal integrators, a path ray whose vertex stage found the path    \
+     ended), else the material class of the vertex (leaf record); lanes 0..3 reserve for the four rings in one add */  \
+  [[maybe_unused]] auto hand_to_vertex = [&](bool complete, uint32_t nw, uint32_t slot_) {                              \
+    uint32_t cls_ = 0;                                                                                                  \
+    if (complete && (nw & CF_FOUND) && !(nw & CF_KILL_R) && A.integrator >= VIMG_INTEGRATOR_MATERIAL) {                 \
+      cls_ = (nw >> CF_CLS_SHIFT) & 3u;                                                                                 \
+      if (cls_ == 0 && material_mode) cls_ = 3; /* material_integrator shades emitters too */                           \
+      if (cls_ != 0) {                                                                                                  \
+        if (A.pool_classes == 1) cls_ = 1;                                                                              \
+        else if (A.pool_classes == 2) cls_ = (cls_ == 2) ? 2u : 1u;                                                     \
+      }                                                                                                                 \
+    }                                                                                                                   \
+    const unsigned long long m0_ = __ballot(complete && cls_ == 0), m1_ = __ballot(complete && cls_ == 1),              \
+                             m2_ = __ballot(complete && cls_ == 2), m3_ = __ballot(complete && cls_ == 3);              \
+    if ((m0_ | m1_ | m2_ | m3_) == 0ull) return;                                                                        \
+    const uint32_t n_me_ = static_cast<uint32_t>(__popcll(lane == 0 ? m0_ : (lane == 1 ? m1_ : (lane == 2 ? m2_ : m3_)))); \
+    uint32_t t_me_ = 0;                                                                                                 \
+    if (lane < 4u && n_me_ != 0u) {                                                                                     \
+      t_me_ = lds_add_rtn(&G->tail[lane], n_me_);                                                                       \
+      if (t_me_ > 0x7ff00000u) raise(8u);                                                                               \
+    }                                                                                                                   \
+    const uint32_t t0_ = __shfl(t_me_, 0), t1_ = __shfl(t_me_, 1), t2_ = __shfl(t_me_, 2), t3_ = __shfl(t_me_, 3);      \
+    if (complete) {                                                                                                     \
+      const uint32_t tt_ = cls_ == 0 ? t0_ : (cls_ == 1 ? t1_ : (cls_ == 2 ? t2_ : t3_));                               \
+      const unsigned long long mm_ = cls_ == 0 ? m0_ : (cls_ == 1 ? m1_ : (cls_ == 2 ? m2_ : m3_));                     \
+      *ring_at(cls_, tt_ + lane_rank(mm_, lane)) = static_cast<uint16_t>(slot_);                                        \
+      if (full_stats) tq[slot_] = static_cast<uint32_t>(__builtin_readcyclecounter());                                  \
+    }                                                                                                                   \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                                                              \
+    if (lane < 4u && n_me_ != 0u) lds_add_rtn(&G->avail[lane], static_cast<int32_t>(n_me_));                            \
+  };                                                                                                                    \
+  /* the rays of the lanes of `ms_` (shadow rays) and `mr_` (path rays) into the walk ring, one reservation, shadow    \
+     rays first (an occluded one is the shorter walk, and rays of a kind are then walked together) */                   \
+  [[maybe_unused]] auto push_rays = [&](bool is_s, bool is_r, uint32_t slot_) {                                         \
+    const unsigned long long ms_ = __ballot(is_s), mr_ = __ballot(is_r);                                                \
+    const uint32_t n_s_ = static_cast<uint32_t>(__popcll(ms_)), n_r_ = static_cast<uint32_t>(__popcll(mr_));            \
+    if (n_s_ + n_r_ == 0u) return;                                                                                      \
+    uint32_t t_ = 0;                                                                                                    \
+    if (lane == 0) {                                                                                                    \
+      t_ = lds_add_rtn(&G->tail[CQ_WALK], n_s_ + n_r_);                                                                 \
+      if (t_ > 0x7ff00000u) raise(8u);                                                                                  \
+    }                                                                                                                   \
+    t_ = cu_uni(t_);                                                                                                    \
+    if (is_s) *ring_at(CQ_WALK, t_ + lane_rank(ms_, lane)) = static_cast<uint16_t>(slot_ | CU_RAY_S);                   \
+    if (is_r) *ring_at(CQ_WALK, t_ + n_s_ + lane_rank(mr_, lane)) = static_cast<uint16_t>(slot_);                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                                                              \
+    if (lane == 0) lds_add_rtn(&G->avail[CQ_WALK], static_cast<int32_t>(n_s_ + n_r_));                                  \
+  };                                                                                                                    \
   /* pop: up to `want` entries (wave-uniform); the lanes of `takers` (at least `want` of them) receive them in rank    \
      order; returns the number taken.  An entry whose producer has reserved but not yet written reads EMPTY. */         \
   [[maybe_unused]] auto pop = [&](uint32_t q, uint32_t want, unsigned long long takers, uint32_t& entry) -> uint32_t {   \
@@ -247,7 +303,7 @@ VD CuKPtr cu_kargs() {
 // (the body is render_pool4_kernel's vertex stage; FIN: the finisher queue, MTC: material the shading
 // is specialised for, -1 = any).  `n` slots; lane i < n holds its slot id in `slot`.
 template <bool TEX, int NW, bool DIAG, bool FIN, int MTC>
-VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan) {
+VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan, uint32_t& n_dead) {
   const CuKPtr K = cu_kargs();
   CU_STAGE_LOCALS(K);
   constexpr bool finisher_batch = FIN;
@@ -327,7 +383,7 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan)
     // next-event estimation of the previous vertex (mis_integrator.cpp:64-78)
     if ((flags & CF_HAS_S) && !(flags & CF_OCCLUDED))
       result = result + f3{uf(r_nee.x), uf(r_nee.y), uf(r_nee.z)};
-    if (!(flags & CF_HAS_R)) {
+    if (!(flags & CF_HAS_R) || (flags & CF_KILL_R)) {
       finish = true;   // the BSDF sample failed there: return bounce_result (:86-88,:108-114)
     } else {
       const bool hit_any = (flags & CF_FOUND) != 0;
@@ -425,6 +481,7 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan)
   pv_lap(1);
   // ---- the next rays of a vertex
   bool has_s = false, has_r = false;
+  bool early = false, pushed_r = false;   // EARLY launches: this lane queues its rays before the end of the stage / has queued its path ray
   f3 shadow_d{0.f, 0.f, 1.f}, nee_contrib{0.f, 0.f, 0.f};
   float shadow_max_t = 0.f;
   // (a finisher batch never holds a vertex to shade: the walk sends every hit on a non-emitter to
@@ -485,27 +542,51 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan)
       }
       at_vertex = false;
     }
+    // mis_integrator.cpp:45-122 in three phases (draw order: light pick + emitter sample, then
+    // sample_mat, then the two evaluations).  Between the phases - at wave level, every lane
+    // there - the EARLY build of a launch queues each ray as soon as it is known: the shadow ray
+    // after the light sample, the path ray after the BSDF sample, so that both are being walked
+    // while this wave still evaluates the BSDF twice and stores the slot's state.  On a frame short
+    // of pixels the last pixels' chains of (vertex stage, walk) hops are the frame time, and the
+    // walk then runs beside the second half of the vertex stage instead of behind it.  A slot is
+    // complete when its rays AND its vertex stage have finished (CF_DONE_V, the last OR decides).
+    constexpr int MT = MTC;
+    const bool early_on = (A.cu_flex & 32u) != 0u;
+    uint32_t mat_type = 0u;
+    float hit_dist = 0.f, surface_spread_angle = 0.f;
+    f3 light_col{0.f, 0.f, 0.f};
+    EmitterInfo li{f3{0.f, 0.f, 1.f}, 0.f, 0.f, 0.f};
+    bool nee = false, reg_before = false;
+    RayCone nee_cone = cone;
+    Scatter sc = no_scatter();
     if (at_vertex) {
-      constexpr int MT = MTC;
-      // mis_integrator.cpp:45-122.  Draw order: light pick + emitter sample, then sample_mat.
-      const uint32_t mat_type = MT >= 0 ? uint32_t(MT) : g.materials[hit.mat].type;
-      float hit_dist = 0.f, surface_spread_angle = 0.f;
+      mat_type = MT >= 0 ? uint32_t(MT) : g.materials[hit.mat].type;
       if constexpr (TEX) {
         hit_dist = length(ray_o - hit.p);
         surface_spread_angle = spread_angle_from_curvature(hit.curvature, cone.cone_width, ray_d, hit.ns);
       }
-      f3 light_col{0.f, 0.f, 0.f};
-      EmitterInfo li{f3{0.f, 0.f, 1.f}, 0.f, 0.f, 0.f};
-      bool nee = false;
       if (mat_type != VIMG_MAT_DIELECTRIC) {   // !is_delta
         lights_sample<TEX>(g, hit.p, rng, light_col, li);
         nee = (li.pdf != 0.f);
       }
-      pv_lap(2);
-      const bool reg_before = non_specular_bounce;
-      RayCone nee_cone = cone;
-      Scatter sc = sample_mat<TEX, MT>(g, hit, ray_d, rng, reg_before);
-      pv_lap(3);
+      reg_before = non_specular_bounce;
+    }
+    early = early_on && at_vertex && !mirror;
+    if (early_on) {
+      if (early) {
+        // origin of both rays, the shadow ray, and the flag word the walkers will OR into (nobody
+        // else touches it yet): written before the first ray is queued
+        wr(CR_ORG, slot, v4u{fu(hit.p.x), fu(hit.p.y), fu(hit.p.z), fu(li.dist - 0.0001f)});
+        if (nee) wr(CR_SHD, slot, v4u{fu(li.wi.x), fu(li.wi.y), fu(li.wi.z), hops});
+        else if (full_stats) recw[(CR_SHD * P + slot) * 4u + 3u] = hops;
+        *flag_word(slot) = (nee ? CF_HAS_S : 0u) | (reg_before ? CF_NONSPEC : 0u) | (bounce << CF_BOUNCE_SHIFT);
+        if (full_stats) tq[slot] = static_cast<uint32_t>(__builtin_readcyclecounter());
+      }
+      push_rays(early && nee, false, slot);
+    }
+    pv_lap(2);
+    if (at_vertex) {
+      sc = sample_mat<TEX, MT>(g, hit, ray_d, rng, reg_before);
       if constexpr (TEX) nee_cone = propagate_reflect_cone(cone, surface_spread_angle * 2.f, hit_dist);
       if (sc.valid) {
         if (!sc.is_specular) non_specular_bounce = true;
@@ -516,8 +597,21 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan)
           if constexpr (TEX) cone = nee_cone;
         }
       }
-      // both BSDF evaluations happen before either ray is traced: the evaluation towards the
-      // light is pure, so doing it for a light that turns out occluded changes nothing; its
+    }
+    pushed_r = early && sc.valid;
+    if (early_on) {
+      if (pushed_r) {
+        // the path ray's direction beside the flag word (three dwords: the word itself belongs to the atomics now)
+        VIMG_LDS uint32_t* dw = recw + (CR_DIR * P + slot) * 4u;
+        dw[0] = fu(sc.wo.x), dw[1] = fu(sc.wo.y), dw[2] = fu(sc.wo.z);
+        __hip_atomic_fetch_or(flag_word(slot), CF_HAS_R | (non_specular_bounce ? CF_NONSPEC : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      push_rays(false, pushed_r, slot);
+    }
+    pv_lap(3);
+    if (at_vertex) {
+      // both BSDF evaluations happen before either ray's result is looked at: the evaluation towards
+      // the light is pure, so doing it for a light that turns out occluded changes nothing; its
       // regularisation flag is the one from BEFORE this bounce
       f3 f_l{0.f, 0.f, 0.f}, f_s{0.f, 0.f, 0.f};   // towards the light / along the sampled direction
       float pdf_l = 0.f, pdf_s = 0.f;
@@ -712,15 +806,17 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan)
   // ---- registers -> slot state, slot -> walk ring (both rays of the vertex at once) or finisher ring
   const bool keep = on && !retire && !mirror;
   if (keep) {
-    // a slot that waits for its item's previous segment stays "fresh" and keeps the claim
-    const uint32_t nf = pending ? (CF_FRESH | CF_PRIMARY)
-                                : ((primary ? CF_PRIMARY : 0u) | (non_specular_bounce ? CF_NONSPEC : 0u) |
-                                   (has_s ? CF_HAS_S : 0u) | (has_r ? CF_HAS_R : 0u) | (bounce << CF_BOUNCE_SHIFT));
-    if (pending) has_s = false, has_r = false, smp = claim;
-    wr(CR_ORG, slot, v4u{fu(ray_o.x), fu(ray_o.y), fu(ray_o.z), fu(shadow_max_t)});
-    wr(CR_DIR, slot, v4u{fu(ray_d.x), fu(ray_d.y), fu(ray_d.z), nf});
-    if (has_s) wr(CR_SHD, slot, v4u{fu(shadow_d.x), fu(shadow_d.y), fu(shadow_d.z), hops});
-    else if (full_stats) recw[(CR_SHD * P + slot) * 4u + 3u] = hops;
+    if (!early) {
+      // a slot that waits for its item's previous segment stays "fresh" and keeps the claim
+      const uint32_t nf = pending ? (CF_FRESH | CF_PRIMARY)
+                                  : ((primary ? CF_PRIMARY : 0u) | (non_specular_bounce ? CF_NONSPEC : 0u) |
+                                     (has_s ? CF_HAS_S : 0u) | (has_r ? CF_HAS_R : 0u) | CF_DONE_V | (bounce << CF_BOUNCE_SHIFT));
+      if (pending) has_s = false, has_r = false, smp = claim;
+      wr(CR_ORG, slot, v4u{fu(ray_o.x), fu(ray_o.y), fu(ray_o.z), fu(shadow_max_t)});
+      wr(CR_DIR, slot, v4u{fu(ray_d.x), fu(ray_d.y), fu(ray_d.z), nf});
+      if (has_s) wr(CR_SHD, slot, v4u{fu(shadow_d.x), fu(shadow_d.y), fu(shadow_d.z), hops});
+      else if (full_stats) recw[(CR_SHD * P + slot) * 4u + 3u] = hops;
+    }
     cwr(SC_THROUGHPUT, slot, v4u{fu(throughput.x), fu(throughput.y), fu(throughput.z), fu(eta_scale)});
     cwr(SC_RESULT, slot, v4u{fu(result.x), fu(result.y), fu(result.z), fu(prev_pdf)});
     if (has_s) cwr(SC_NEE, slot, v4u{fu(nee_contrib.x), fu(nee_contrib.y), fu(nee_contrib.z), 0u});
@@ -728,30 +824,35 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan)
     if (finisher_batch) cold_acc[slot] = v4u{fu(acc.x), fu(acc.y), fu(acc.z), item};
     if constexpr (TEX) cold_cone[slot] = v4u{fu(cone.cone_width), fu(cone.spread_angle), 0u, 0u};
   }
-  if (full_stats && keep) tq[slot] = static_cast<uint32_t>(__builtin_readcyclecounter());
+  if (full_stats && keep && !early) tq[slot] = static_cast<uint32_t>(__builtin_readcyclecounter());
   // the next stage of a slot may run on another wave of the CU: its cold records must have left
   // this wave before the slot id does (same L1: performed = visible)
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   {
-    // one reservation for both kinds of ray: shadow rays first (an occluded one is the shorter walk)
-    const unsigned long long ms = __ballot(keep && has_s), mr = __ballot(keep && has_r);
-    const uint32_t n_s = static_cast<uint32_t>(__popcll(ms)), n_r = static_cast<uint32_t>(__popcll(mr));
-    if (n_s + n_r != 0u) {
-      uint32_t t = 0;
-      if (lane == 0) {
-        t = lds_add_rtn(&G->tail[CQ_WALK], n_s + n_r);
-        if (t > 0x7ff00000u) raise(8u);
-      }
-      t = cu_uni(t);
-      if (keep && has_s) *ring_at(CQ_WALK, t + lane_rank(ms, lane)) = static_cast<uint16_t>(slot | CU_RAY_S);
-      if (keep && has_r) *ring_at(CQ_WALK, t + n_s + lane_rank(mr, lane)) = static_cast<uint16_t>(slot);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) lds_add_rtn(&G->avail[CQ_WALK], static_cast<int32_t>(n_s + n_r));
-    }
+    // (lanes that have not queued their rays yet) one reservation for both kinds of ray
+    push_rays(keep && !early && has_s, keep && !early && has_r, slot);
     // a path that ended here goes to the finisher ring; so do slots that wait for a segment
-    push(0u, __ballot(keep && !has_s && !has_r), slot);
+    push(0u, __ballot(keep && !early && !has_s && !has_r), slot);
     const uint32_t n_retired = static_cast<uint32_t>(__popcll(__ballot(on && retire)));
     if (n_retired && lane == 0) __hip_atomic_fetch_sub(&G->live, n_retired, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  if constexpr (!FIN) {
+    if (cu_uni(A.cu_flex) & 32u) {
+      // lanes whose rays are already out: the state is written; if both rays have been walked meanwhile
+      // this OR completes the slot and this wave hands it on.  A path ray queued before the evaluation found
+      // the path ended (NaN pdf) is walked for nothing: its result is marked dead and the ray is not counted
+      // (the reference never traced it).
+      const bool mine = keep && early, dead = mine && pushed_r && !has_r;
+      uint32_t nw = 0;
+      bool complete = false;
+      if (mine) {
+        const uint32_t orv = CF_DONE_V | (dead ? CF_KILL_R : 0u);
+        nw = __hip_atomic_fetch_or(flag_word(slot), orv, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) | orv;
+        complete = slot_complete(nw);
+      }
+      hand_to_vertex(complete, nw, slot);
+      n_dead += static_cast<uint32_t>(__popcll(__ballot(dead)));
+    }
   }
   pv_lap(5);
   if constexpr (PV) {
@@ -958,12 +1059,13 @@ VD void cu_walk(uint32_t& n_closest, uint32_t& n_shadow) {
       if (n_act == 0 || n_fin >= A.pool_refill) break;
     }
 
-    // (4) finished rays: result into the slot, OR into its flag word; the ray that completes the
-    // vertex (the only one, or the second of two) hands the slot to the vertex ring of its class
+    // (4) finished rays: result into the slot, OR into its flag word; whoever completes the slot - a
+    // ray, or the vertex stage that queued it when that one finishes last - hands it to the vertex
+    // ring of its class
     {
       const bool done = w_slot != SLOT_IDLE && cur == REF_DONE;
       bool complete = false;
-      uint32_t cls = 0;
+      uint32_t nw = 0;
       if (done) {
         uint32_t orv;
         if (w_type == 0u) {
@@ -976,40 +1078,11 @@ VD void cu_walk(uint32_t& n_closest, uint32_t& n_shadow) {
             hitx[w_slot] = v2u{rec.prim, fu(ray.max_t)};
           }
         }
-        const uint32_t nw = __hip_atomic_fetch_or(flag_word(w_slot), orv, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) | orv;
-        complete = (!(nw & CF_HAS_S) || (nw & CF_DONE_S)) && (!(nw & CF_HAS_R) || (nw & CF_DONE_R));
-        // class of the batch the slot joins: 0 = its path ends (miss, no path ray, emitter hit under
-        // mis, any hit under the normal integrators), else the material class of the vertex
-        if (complete && (nw & CF_FOUND) && A.integrator >= VIMG_INTEGRATOR_MATERIAL) {
-          cls = (nw >> CF_CLS_SHIFT) & 3u;
-          if (cls == 0 && material_mode) cls = 3;   // material_integrator shades emitters too
-          if (cls != 0) {
-            if (A.pool_classes == 1) cls = 1;
-            else if (A.pool_classes == 2) cls = (cls == 2) ? 2u : 1u;
-          }
-        }
+        nw = __hip_atomic_fetch_or(flag_word(w_slot), orv, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) | orv;
+        complete = slot_complete(nw);
       }
       if (__any(done)) {
-        const unsigned long long m0 = __ballot(complete && cls == 0), m1 = __ballot(complete && cls == 1),
-                                 m2 = __ballot(complete && cls == 2), m3 = __ballot(complete && cls == 3);
-        if ((m0 | m1 | m2 | m3) != 0ull) {
-          // lanes 0..3 reserve for the four rings in one returning add
-          const uint32_t n_me = static_cast<uint32_t>(__popcll(lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : m3))));
-          uint32_t t_me = 0;
-          if (lane < 4u && n_me != 0u) {
-            t_me = lds_add_rtn(&G->tail[lane], n_me);
-            if (t_me > 0x7ff00000u) raise(8u);
-          }
-          const uint32_t t0 = __shfl(t_me, 0), t1 = __shfl(t_me, 1), t2 = __shfl(t_me, 2), t3 = __shfl(t_me, 3);
-          if (complete) {
-            const uint32_t t = cls == 0 ? t0 : (cls == 1 ? t1 : (cls == 2 ? t2 : t3));
-            const unsigned long long m = cls == 0 ? m0 : (cls == 1 ? m1 : (cls == 2 ? m2 : m3));
-            *ring_at(cls, t + lane_rank(m, lane)) = static_cast<uint16_t>(w_slot);
-            if (full_stats) tq[w_slot] = static_cast<uint32_t>(__builtin_readcyclecounter());
-          }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          if (lane < 4u && n_me != 0u) lds_add_rtn(&G->avail[lane], static_cast<int32_t>(n_me));
-        }
+        hand_to_vertex(complete, nw, w_slot);
         if (full_stats && done) {
           __hip_atomic_fetch_add(&wrec->ray_cyc, static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_readcyclecounter()) - t_in), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           __hip_atomic_fetch_add(&wrec->ray_n, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1067,6 +1140,7 @@ render_cu_kernel(const CuKArgs ka) {
   }
   // wave-uniform event counts (scalar registers): the two ray counts every stats launch reports
   uint32_t n_closest = 0, n_shadow = 0, n_nan = 0, iter_wave = 0;
+  uint32_t n_dead = 0;   // path rays queued early and walked for nothing (their vertex found the path ended): not counted, as the reference never traced them
   unsigned long long t_mark = __builtin_readcyclecounter();
   bool skip_fin = false;   // the last finisher batch of this wave held only slots that wait for another slot's segment
   uint32_t polls = 0;      // looks that found nothing to do
@@ -1130,13 +1204,13 @@ render_cu_kernel(const CuKArgs ka) {
       const bool by_class = A.pool_classes == 3u;
       if (A.cu_flex & 2u) __builtin_amdgcn_s_setprio(1);
       if (cls == 0u)
-        cu_vertex<TEX, NW, DIAG, true, -1>(n, e, all_pending, n_nan);
+        cu_vertex<TEX, NW, DIAG, true, -1>(n, e, all_pending, n_nan, n_dead);
       else if (cls == 1u && by_class)
-        cu_vertex<TEX, NW, DIAG, false, int(VIMG_MAT_LAMBERTIAN)>(n, e, all_pending, n_nan);
+        cu_vertex<TEX, NW, DIAG, false, int(VIMG_MAT_LAMBERTIAN)>(n, e, all_pending, n_nan, n_dead);
       else if (cls == 2u && by_class)
-        cu_vertex<TEX, NW, DIAG, false, int(VIMG_MAT_PRINCIPLED)>(n, e, all_pending, n_nan);
+        cu_vertex<TEX, NW, DIAG, false, int(VIMG_MAT_PRINCIPLED)>(n, e, all_pending, n_nan, n_dead);
       else
-        cu_vertex<TEX, NW, DIAG, false, -1>(n, e, all_pending, n_nan);
+        cu_vertex<TEX, NW, DIAG, false, -1>(n, e, all_pending, n_nan, n_dead);
       if (A.cu_flex & 2u) __builtin_amdgcn_s_setprio(0);
       skip_fin = all_pending;
       if (!all_pending) polls = 0, idle_since = 0;   // (a batch of waiting slots only is not progress: the watchdog keeps its time)
@@ -1173,7 +1247,7 @@ render_cu_kernel(const CuKArgs ka) {
     DeviceStats* __restrict__ stats = K->stats;
     if (full_stats && lane == 0) wrec->cyc[5] += __builtin_readcyclecounter() - t_mark;
     if (stats && lane == 0) {
-      atomicAdd(&stats->closest, static_cast<unsigned long long>(n_closest));
+      atomicAdd(&stats->closest, static_cast<unsigned long long>(n_closest) - static_cast<unsigned long long>(n_dead));   // (modulo 2^64: the sum over the waves is what counts)
       atomicAdd(&stats->shadow, static_cast<unsigned long long>(n_shadow));
       if (n_nan) atomicAdd(&stats->nan_samples, static_cast<unsigned long long>(n_nan));
       if (full_stats) {

@@ -360,7 +360,7 @@ LaunchCfg make_launch_cu(const VimgDeviceScene* s, const VimgRenderParams* p, in
   // walking waves: five of eight by policy (config 2: the walk is 60 % of the wave cycles); when every
   // wave walks, every wave must be allowed to shade too
   a.cu_walkers = 0;   // (set below, once the tree's place is known)
-  a.cu_flex = opt_or(o.cu_flex, 1u);   // (bit 1 / 2: shading / walking at wave priority 1; bit 4: no split batches)
+  a.cu_flex = opt_or(o.cu_flex, 1u);   // (bit 1 / 2: shading / walking at wave priority 1; bit 4: no split batches; bit 5: early rays, by policy below)
   a.cu_lowwater = std::max(1u, opt_or(o.cu_lowwater, 64u));
   a.cu_patience = opt_or(o.cu_patience, 4u);
   a.cu_join = std::max(1u, opt_or(o.cu_join, 1u));
@@ -425,6 +425,13 @@ LaunchCfg make_launch_cu(const VimgDeviceScene* s, const VimgRenderParams* p, in
     slots = static_cast<uint32_t>(per_group * 10u / 27u);
   slots = static_cast<uint32_t>(std::min<uint64_t>(slots, per_group + 8u));
   slots = std::max(slots & ~7u, 8u);
+  // EARLY rays (cu_flex bit 5: a vertex stage queues each ray as soon as it is known and finishes beside
+  // the walk) wherever a slot's hop latency is on the frame's critical path: launches of fewer than three
+  // pools' worth of pixels, and trees in global memory (whose walks are long).  Config 2: an eighth 110.4 ->
+  // 99.9 ms, a quarter 132.5 -> 118.3, a half 170.6 -> 164.5, the whole frame 300.4 -> 309.7 (it only pays the
+  // two extra ring operations per vertex: off there); stand-ins of configs 4 / 5: whole frame 121.4 -> 118.4 /
+  // 127.0 -> 124.1, an eighth 81.3 -> 79.4 / 76.8 -> 69.9
+  if (o.cu_flex == VIMG_OPT_AUTO && (c.deep || per_group * 10u <= uint64_t(slots) * 30u)) a.cu_flex |= 32u;
   a.pool_slots = slots;
   magic_div(slots, &a.cu_magic_v, &a.cu_shift_v);
   magic_div(2u * slots, &a.cu_magic_w, &a.cu_shift_w);
