@@ -542,14 +542,16 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan,
       }
       at_vertex = false;
     }
-    // mis_integrator.cpp:45-122 in three phases (draw order: light pick + emitter sample, then
-    // sample_mat, then the two evaluations).  Between the phases - at wave level, every lane
-    // there - the EARLY build of a launch queues each ray as soon as it is known: the shadow ray
-    // after the light sample, the path ray after the BSDF sample, so that both are being walked
-    // while this wave still evaluates the BSDF twice and stores the slot's state.  On a frame short
-    // of pixels the last pixels' chains of (vertex stage, walk) hops are the frame time, and the
-    // walk then runs beside the second half of the vertex stage instead of behind it.  A slot is
-    // complete when its rays AND its vertex stage have finished (CF_DONE_V, the last OR decides).
+    // mis_integrator.cpp:45-122 in three phases.  The DRAW order is the reference's: light pick +
+    // emitter sample (always six draws), then sample_mat - but the BSDF sample is COMPUTED first,
+    // from the state six draws on (pcg_skip6), and the light sample after it from the state as it
+    // was: same numbers, and the path ray - the one whose walk the next vertex waits for - is known
+    // a light sample earlier.  Between the phases - at wave level, every lane there - the EARLY
+    // build of a launch queues each ray as soon as it is known, so that both are being walked
+    // while this wave still samples the light, evaluates the BSDF twice and stores the slot's
+    // state.  On a frame short of pixels the last pixels' chains of (vertex stage, walk) hops are
+    // the frame time, and the walk then runs beside most of the vertex stage instead of behind it.
+    // A slot is complete when its rays AND its vertex stage have finished (CF_DONE_V, the last OR decides).
     constexpr int MT = MTC;
     const bool early_on = (A.cu_flex & 32u) != 0u;
     uint32_t mat_type = 0u;
@@ -559,33 +561,16 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan,
     bool nee = false, reg_before = false;
     RayCone nee_cone = cone;
     Scatter sc = no_scatter();
+    Rng rng_l{0};   // the stream where the light sample draws
     if (at_vertex) {
       mat_type = MT >= 0 ? uint32_t(MT) : g.materials[hit.mat].type;
       if constexpr (TEX) {
         hit_dist = length(ray_o - hit.p);
         surface_spread_angle = spread_angle_from_curvature(hit.curvature, cone.cone_width, ray_d, hit.ns);
       }
-      if (mat_type != VIMG_MAT_DIELECTRIC) {   // !is_delta
-        lights_sample<TEX>(g, hit.p, rng, light_col, li);
-        nee = (li.pdf != 0.f);
-      }
       reg_before = non_specular_bounce;
-    }
-    early = early_on && at_vertex && !mirror;
-    if (early_on) {
-      if (early) {
-        // origin of both rays, the shadow ray, and the flag word the walkers will OR into (nobody
-        // else touches it yet): written before the first ray is queued
-        wr(CR_ORG, slot, v4u{fu(hit.p.x), fu(hit.p.y), fu(hit.p.z), fu(li.dist - 0.0001f)});
-        if (nee) wr(CR_SHD, slot, v4u{fu(li.wi.x), fu(li.wi.y), fu(li.wi.z), hops});
-        else if (full_stats) recw[(CR_SHD * P + slot) * 4u + 3u] = hops;
-        *flag_word(slot) = (nee ? CF_HAS_S : 0u) | (reg_before ? CF_NONSPEC : 0u) | (bounce << CF_BOUNCE_SHIFT);
-        if (full_stats) tq[slot] = static_cast<uint32_t>(__builtin_readcyclecounter());
-      }
-      push_rays(early && nee, false, slot);
-    }
-    pv_lap(2);
-    if (at_vertex) {
+      rng_l = rng;
+      if (mat_type != VIMG_MAT_DIELECTRIC) pcg_skip6(rng);   // (!is_delta: the light sample's six draws)
       sc = sample_mat<TEX, MT>(g, hit, ray_d, rng, reg_before);
       if constexpr (TEX) nee_cone = propagate_reflect_cone(cone, surface_spread_angle * 2.f, hit_dist);
       if (sc.valid) {
@@ -598,17 +583,36 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan,
         }
       }
     }
+    early = early_on && at_vertex && !mirror;
     pushed_r = early && sc.valid;
     if (early_on) {
-      if (pushed_r) {
-        // the path ray's direction beside the flag word (three dwords: the word itself belongs to the atomics now)
-        VIMG_LDS uint32_t* dw = recw + (CR_DIR * P + slot) * 4u;
-        dw[0] = fu(sc.wo.x), dw[1] = fu(sc.wo.y), dw[2] = fu(sc.wo.z);
-        __hip_atomic_fetch_or(flag_word(slot), CF_HAS_R | (non_specular_bounce ? CF_NONSPEC : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (early) {
+        // origin of both rays, the path ray and the flag word the walkers will OR into (nobody else
+        // touches it yet): written before the first ray is queued
+        wr(CR_ORG, slot, v4u{fu(hit.p.x), fu(hit.p.y), fu(hit.p.z), 0u});
+        wr(CR_DIR, slot, v4u{fu(sc.wo.x), fu(sc.wo.y), fu(sc.wo.z),
+                             (sc.valid ? CF_HAS_R : 0u) | (non_specular_bounce ? CF_NONSPEC : 0u) | (bounce << CF_BOUNCE_SHIFT)});
+        if (full_stats) tq[slot] = static_cast<uint32_t>(__builtin_readcyclecounter());
       }
       push_rays(false, pushed_r, slot);
     }
     pv_lap(3);
+    if (at_vertex && mat_type != VIMG_MAT_DIELECTRIC) {
+      lights_sample<TEX>(g, hit.p, rng_l, light_col, li);
+      nee = (li.pdf != 0.f);
+    }
+    if (early_on) {
+      if (early && nee) {
+        // the shadow ray and its reach beside a record whose other words a walker may be reading: one dword
+        recw[(CR_ORG * P + slot) * 4u + 3u] = fu(li.dist - 0.0001f);
+        wr(CR_SHD, slot, v4u{fu(li.wi.x), fu(li.wi.y), fu(li.wi.z), hops});
+        __hip_atomic_fetch_or(flag_word(slot), CF_HAS_S, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else if (early && full_stats) {
+        recw[(CR_SHD * P + slot) * 4u + 3u] = hops;
+      }
+      push_rays(early && nee, false, slot);
+    }
+    pv_lap(2);
     if (at_vertex) {
       // both BSDF evaluations happen before either ray's result is looked at: the evaluation towards
       // the light is pure, so doing it for a light that turns out occluded changes nothing; its

@@ -44,6 +44,17 @@ VD void pcg_seed(Rng& r, uint64_t initstate) {
   r.s += initstate;
   pcg_next(r);
 }
+// Six draws ahead in one step: state * a^6 + (a^5 + a^4 + a^3 + a^2 + a + 1) (the stream's increment is 1).
+// A light sample always takes six draws (GroupOfEmitters::sample: one rand_float for the pick, two in
+// every emitter's sample(), two pcg draws each: include/geometry/emitters.h:39-56, src/geometry/
+// {triangle,sphere}.cpp, include/background.h), so the BSDF sample that follows it in the stream can
+// be computed first from the state six draws on.
+constexpr uint64_t kPcgA = 6364136223846793005ULL;
+constexpr uint64_t pcg_a_pow(int n) { uint64_t r = 1; for (int i = 0; i < n; ++i) r *= kPcgA; return r; }
+constexpr uint64_t pcg_c_sum(int n) { uint64_t r = 0; for (int i = 0; i < n; ++i) r += pcg_a_pow(i); return r; }
+constexpr uint64_t pcg_step_n(uint64_t s, int n) { for (int i = 0; i < n; ++i) s = s * kPcgA + 1ULL; return s; }
+static_assert(pcg_step_n(0x853c49e6748fea9bULL, 6) == 0x853c49e6748fea9bULL * pcg_a_pow(6) + pcg_c_sum(6), "six LCG steps in one");
+VD void pcg_skip6(Rng& r) { r.s = r.s * pcg_a_pow(6) + pcg_c_sum(6); }
 // rand_float: reference include/rng/sampling.h:85-105
 VD float rand_float(Rng& r) {
   uint64_t r1 = pcg_next(r);

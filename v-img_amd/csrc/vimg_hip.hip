@@ -432,6 +432,10 @@ LaunchCfg make_launch_cu(const VimgDeviceScene* s, const VimgRenderParams* p, in
   // two extra ring operations per vertex: off there); stand-ins of configs 4 / 5: whole frame 121.4 -> 118.4 /
   // 127.0 -> 124.1, an eighth 81.3 -> 79.4 / 76.8 -> 69.9
   if (o.cu_flex == VIMG_OPT_AUTO && (c.deep || per_group * 10u <= uint64_t(slots) * 30u)) a.cu_flex |= 32u;
+  // a tree in global memory on a launch whose pixels all own a slot: the box loop yields to waiting leaves
+  // below 8 descending lanes instead of 16 (stand-ins of configs 4 / 5, a quarter at 128 spp: 79.3 / 69.9
+  // against 80.8 / 72.7 ms, an eighth 76.7 / 65.5 against 76.9 / 70.1; halves and whole frames want 16)
+  if (c.deep && o.pool_boxmin == VIMG_OPT_AUTO && per_group + 8u >= slots && per_group <= slots) a.pool_boxmin = 8u;
   a.pool_slots = slots;
   magic_div(slots, &a.cu_magic_v, &a.cu_shift_v);
   magic_div(2u * slots, &a.cu_magic_w, &a.cu_shift_w);
