@@ -44,7 +44,7 @@ $(OBJDIR)/%.o: v-img_amd/csrc/%.hip $(HIPHDR) Makefile
 # of them (the f64 polynomial coefficients of acos / atan2 / pow ...) in front of the loop, where they
 # no longer fit the register file: 533 spilled registers and 700 bytes of scratch per lane with the
 # pass, 80 / 72 without (tools/kres.sh)
-$(OBJDIR)/k_cu.o $(OBJDIR)/k_cu_diag.o: HIPCFLAGS += -mllvm -disable-machine-licm
+$(OBJDIR)/k_cu.o $(OBJDIR)/k_cu_early.o $(OBJDIR)/k_cu_diag.o: HIPCFLAGS += -mllvm -disable-machine-licm
 $(LIBDIR)/libvimg_hip.so: $(HIPOBJ)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(HIPOBJ) -o $@

@@ -24,7 +24,7 @@ rays = round(line["value"] * 1e6 * line["ms_per_step"] * 1e-3)
 ms = None
 for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv")):
     for r in csv.DictReader(open(f)):
-        if kernel_name.split("<")[0] in r["Name"] and ("render_cu_kernel" not in r["Name"] or ", false>(" in r["Name"]):
+        if kernel_name.split("<")[0] in r["Name"] and ("render_cu_kernel" not in r["Name"] or re.search(r"16, 4, false, \d>", r["Name"])):
             ms = float(r["AverageNs"]) * 1e-6
 tie = {"workload": workload, "kernel_name": kernel_name, "library_sha256": bench.library_fingerprint(),
        "spp": line["config"]["spp"], "rays_per_launch": rays, "ms_per_launch_under_rocprof": ms,

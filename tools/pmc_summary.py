@@ -8,6 +8,7 @@ import collections
 import csv
 import glob
 import json
+import re
 import sys
 
 out_dir = sys.argv[1]
@@ -19,7 +20,7 @@ def wanted(name):
     # the CU scheduler has a build for statistics launches (<..., true>) beside the one frames are timed on
     # (<..., false>): a profile is of the timed one
     if "render_cu_kernel" in name:
-        return ", false>(" in name
+        return re.search(r"16, 4, false, \d>", name) is not None      # <TEX, DEEP, 16, 4, DIAG = false, EARLY>
     return any(n in name for n in KERNELS)
 
 

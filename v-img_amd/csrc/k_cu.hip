@@ -1,4 +1,5 @@
-// render_cu_kernel: one pool per compute unit, walking and shading waves, lock-free rings (the build frames are timed on)
+// render_cu_kernel: one pool per compute unit, walking and shading waves, lock-free rings - the build whole
+// frames are timed on (vertex stages queue their rays at their end)
 #include "kernel_tus.h"
 #include "render_cu_kernel.h"
 
@@ -7,7 +8,7 @@ namespace vimg {
 // 311 ms, halves / quarters of it 207 / 163 against 177 / 149 ms, stand-ins of configs 3-5 7.2 / 2.5 / 3.2
 // against 7.9 / 2.8 / 4.0 Grays/s - the fourth wave per SIMD hides more latency than 40 registers save.)
 CuKernel vimg_cu_kernel(bool tex, bool deep, int) {
-  if (tex) return deep ? render_cu_kernel<true, true, 16, 4, false> : render_cu_kernel<true, false, 16, 4, false>;
-  return deep ? render_cu_kernel<false, true, 16, 4, false> : render_cu_kernel<false, false, 16, 4, false>;
+  if (tex) return deep ? render_cu_kernel<true, true, 16, 4, false, 0> : render_cu_kernel<true, false, 16, 4, false, 0>;
+  return deep ? render_cu_kernel<false, true, 16, 4, false, 0> : render_cu_kernel<false, false, 16, 4, false, 0>;
 }
 }  // namespace vimg

@@ -5,7 +5,7 @@
 
 namespace vimg {
 CuKernel vimg_cu_kernel_diag(bool tex, bool deep, int) {
-  if (tex) return deep ? render_cu_kernel<true, true, 16, 4, true> : render_cu_kernel<true, false, 16, 4, true>;
-  return deep ? render_cu_kernel<false, true, 16, 4, true> : render_cu_kernel<false, false, 16, 4, true>;
+  if (tex) return deep ? render_cu_kernel<true, true, 16, 4, true, 2> : render_cu_kernel<true, false, 16, 4, true, 2>;
+  return deep ? render_cu_kernel<false, true, 16, 4, true, 2> : render_cu_kernel<false, false, 16, 4, true, 2>;
 }
 }  // namespace vimg

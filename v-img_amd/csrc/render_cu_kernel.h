@@ -302,7 +302,7 @@ VD CuKPtr cu_kargs() {
 // ======================================================================== one vertex batch
 // (the body is render_pool4_kernel's vertex stage; FIN: the finisher queue, MTC: material the shading
 // is specialised for, -1 = any).  `n` slots; lane i < n holds its slot id in `slot`.
-template <bool TEX, int NW, bool DIAG, bool FIN, int MTC>
+template <bool TEX, int NW, bool DIAG, int EARLY, bool FIN, int MTC>
 VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan, uint32_t& n_dead) {
   const CuKPtr K = cu_kargs();
   CU_STAGE_LOCALS(K);
@@ -553,7 +553,7 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan,
     // the frame time, and the walk then runs beside most of the vertex stage instead of behind it.
     // A slot is complete when its rays AND its vertex stage have finished (CF_DONE_V, the last OR decides).
     constexpr int MT = MTC;
-    const bool early_on = (A.cu_flex & 32u) != 0u;
+    const bool early_on = EARLY == 2 ? (A.cu_flex & 32u) != 0u : (EARLY == 1);   // (a build of its own: as a runtime branch it costs the whole frame 1.2 %)
     uint32_t mat_type = 0u;
     float hit_dist = 0.f, surface_spread_angle = 0.f;
     f3 light_col{0.f, 0.f, 0.f};
@@ -841,7 +841,7 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan,
     if (n_retired && lane == 0) __hip_atomic_fetch_sub(&G->live, n_retired, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   if constexpr (!FIN) {
-    if (cu_uni(A.cu_flex) & 32u) {
+    if (EARLY == 2 ? (cu_uni(A.cu_flex) & 32u) != 0u : (EARLY == 1)) {
       // lanes whose rays are already out: the state is written; if both rays have been walked meanwhile
       // this OR completes the slot and this wave hands it on.  A path ray queued before the evaluation found
       // the path ended (NaN pdf) is walked for nothing: its result is marked dead and the ray is not counted
@@ -1115,7 +1115,10 @@ VD void cu_walk(uint32_t& n_closest, uint32_t& n_shadow) {
 // DIAG: the build of statistics launches (full_stats): event counts beyond the two ray counts, cycles by
 // stage, ring occupancy and waiting times, passes and lanes of the walk loops, when pixels finish.  The
 // build without them is what a frame is timed on - as runtime branches they cost it 4 % (304 -> 316 ms).
-template <bool TEX, bool DEEP, int NW, int WPS, bool DIAG>
+// EARLY: 1 = vertex stages queue their rays as soon as they are known (cu_flex bit 5, by policy on frames
+// short of pixels and on trees in global memory), 0 = at the end of the stage, 2 = by the bit at run time
+// (the statistics build).
+template <bool TEX, bool DEEP, int NW, int WPS, bool DIAG, int EARLY>
 __global__ void __launch_bounds__(NW * 64, WPS)
 render_cu_kernel(const CuKArgs ka) {
   {
@@ -1208,13 +1211,13 @@ render_cu_kernel(const CuKArgs ka) {
       const bool by_class = A.pool_classes == 3u;
       if (A.cu_flex & 2u) __builtin_amdgcn_s_setprio(1);
       if (cls == 0u)
-        cu_vertex<TEX, NW, DIAG, true, -1>(n, e, all_pending, n_nan, n_dead);
+        cu_vertex<TEX, NW, DIAG, EARLY, true, -1>(n, e, all_pending, n_nan, n_dead);
       else if (cls == 1u && by_class)
-        cu_vertex<TEX, NW, DIAG, false, int(VIMG_MAT_LAMBERTIAN)>(n, e, all_pending, n_nan, n_dead);
+        cu_vertex<TEX, NW, DIAG, EARLY, false, int(VIMG_MAT_LAMBERTIAN)>(n, e, all_pending, n_nan, n_dead);
       else if (cls == 2u && by_class)
-        cu_vertex<TEX, NW, DIAG, false, int(VIMG_MAT_PRINCIPLED)>(n, e, all_pending, n_nan, n_dead);
+        cu_vertex<TEX, NW, DIAG, EARLY, false, int(VIMG_MAT_PRINCIPLED)>(n, e, all_pending, n_nan, n_dead);
       else
-        cu_vertex<TEX, NW, DIAG, false, -1>(n, e, all_pending, n_nan, n_dead);
+        cu_vertex<TEX, NW, DIAG, EARLY, false, -1>(n, e, all_pending, n_nan, n_dead);
       if (A.cu_flex & 2u) __builtin_amdgcn_s_setprio(0);
       skip_fin = all_pending;
       if (!all_pending) polls = 0, idle_since = 0;   // (a batch of waiting slots only is not progress: the watchdog keeps its time)

@@ -295,8 +295,9 @@ StageKernel pick_stage_kernel(const VimgDeviceScene* s, bool deep) { return vimg
 Pool4Kernel pick_pool4_kernel(const VimgDeviceScene* s, bool deep, int wps, bool group) {
   return vimg_pool4_kernel(s->textured, deep, wps, group);
 }
-CuKernel pick_cu_kernel(const VimgDeviceScene* s, bool deep, int nw, bool diag = false) {
-  return diag ? vimg_cu_kernel_diag(s->textured, deep, nw) : vimg_cu_kernel(s->textured, deep, nw);
+CuKernel pick_cu_kernel(const VimgDeviceScene* s, bool deep, int nw, bool diag = false, bool early = false) {
+  return diag ? vimg_cu_kernel_diag(s->textured, deep, nw)
+              : (early ? vimg_cu_kernel_early(s->textured, deep, nw) : vimg_cu_kernel(s->textured, deep, nw));
 }
 const void* kernel_of(const VimgDeviceScene* s, const LaunchCfg& c) {
   if (c.sched == VIMG_SCHED_CU) return reinterpret_cast<const void*>(pick_cu_kernel(s, c.deep, c.cu_waves));
@@ -781,7 +782,8 @@ int enqueue_render(VimgDeviceScene* s, const VimgRenderParams* p, float* d_out, 
   if (want_stats) HIP_TRY(hipMemsetAsync(s->d_stats, 0, sizeof(DeviceStats), st));
   DeviceStats* stats = want_stats ? s->d_stats : nullptr;
   if (c.lds_bytes > 48u * 1024u) {   // ask for the large dynamic-LDS carve-out
-    const void* kfn = (c.sched == VIMG_SCHED_CU && full_stats) ? reinterpret_cast<const void*>(pick_cu_kernel(s, c.deep, c.cu_waves, true)) : kernel_of(s, c);
+    const void* kfn = (c.sched == VIMG_SCHED_CU) ? reinterpret_cast<const void*>(pick_cu_kernel(s, c.deep, c.cu_waves, full_stats, (c.args.cu_flex & 32u) != 0u))
+                                                 : kernel_of(s, c);
     HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, int(c.lds_bytes)));
   }
   if (ev0 && c.sched != VIMG_SCHED_STAGE && c.sched != VIMG_SCHED_POOL4) HIP_TRY(hipEventRecord(ev0, st));
@@ -801,7 +803,8 @@ int enqueue_render(VimgDeviceScene* s, const VimgRenderParams* p, float* d_out, 
     hipLaunchKernelGGL(pick_pool4_kernel(s, c.deep, c.wps, c.group), dim3(c.grid), dim3(256), c.lds_bytes, st,
                        static_cast<const Pool4KArgs*>(blk));
   } else if (c.sched == VIMG_SCHED_CU)
-    hipLaunchKernelGGL(pick_cu_kernel(s, c.deep, c.cu_waves, full_stats), dim3(c.grid), dim3(uint32_t(c.cu_waves) * 64u), c.lds_bytes, st,
+    hipLaunchKernelGGL(pick_cu_kernel(s, c.deep, c.cu_waves, full_stats, (c.args.cu_flex & 32u) != 0u), dim3(c.grid),
+                       dim3(uint32_t(c.cu_waves) * 64u), c.lds_bytes, st,
                        CuKArgs{s->d, c.args, d_out, stats, s->d_counter});
   else
     hipLaunchKernelGGL(pick_kernel(s, c.pooled, c.wps, c.deep), dim3(c.grid), dim3(256), c.lds_bytes, st, s->d, c.args,
