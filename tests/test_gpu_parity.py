@@ -973,6 +973,49 @@ def test_gpu_builders_give_a_valid_tree_and_the_same_picture(name, builder):
     assert same > 0.97 and abs(gpu.mean() - sah_img.mean()) <= 0.03 * abs(sah_img.mean()) + 1e-6
 
 
+def _tree_cost(s):
+    """Surface-area cost of the scene's tree under the reference's model (traversal 0.5, intersection 1:
+    include/bvh.h:17-20): sum over nodes of area / root area x (0.5 for a node with children, its
+    primitive count for a leaf)."""
+    nodes, bb, _, _ = s.bvh_arrays()
+    first, count = nodes[:, 0].astype(np.int64), nodes[:, 1].astype(np.int64)
+
+    def area(lo, hi):
+        d = (hi - lo).astype(np.float64)
+        return d[..., 0] * d[..., 1] + d[..., 0] * d[..., 2] + d[..., 1] * d[..., 2]
+    a = np.zeros(len(nodes))
+    a[0] = area(bb[0], bb[2])
+    inner = np.nonzero(count == 0)[0]
+    base = 2 * first[inner] + 2
+    a[first[inner]] = area(bb[base], bb[base + 2])
+    a[first[inner] + 1] = area(bb[base + 1], bb[base + 3])
+    return float((a * np.where(count == 0, 0.5, count)).sum() / a[0])
+
+
+@pytest.mark.parametrize("builder", ["lbvh", "ploc"])
+def test_gpu_builders_are_deterministic_and_ploc_is_close_to_the_sweep(builder):
+    """The builders' kernels number nodes with atomic counters, but the tree they describe - and so the
+    arrays in the reference's layout - must not depend on the order waves ran in: two builds give the
+    same bytes.  And the quality of vimg_hip_build_ploc is made by its kernels (agglomeration, leaves
+    ended by the cost model, the top rebuilt by binned SAH): on a 27 K-triangle scene its tree costs no
+    more than 1.05 x the host's sweep-SAH tree (src/bvh/sweep_bvh.cpp:74-216, the bar) under the
+    reference's cost model, where the plain LBVH costs more than PLOC."""
+    from vimg_amd import hip
+    s = scenes.config4_scene(res=(96, 54), n_lat=96, env=(64, 32))
+    sweep = _tree_cost(s)
+    fn = hip.lbvh_builder() if builder == "lbvh" else hip.ploc_builder()
+    s.build_bvh_with(fn)
+    first = [np.array(x, copy=True) for x in s.bvh_arrays()[:3]] + [s.bvh_arrays()[3]]
+    cost = _tree_cost(s)
+    s.build_bvh_with(fn)
+    again = s.bvh_arrays()
+    assert all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(first[:3], again[:3])) and first[3] == again[3]
+    if builder == "ploc":
+        assert cost <= 1.05 * sweep, (cost, sweep)
+        s.build_bvh_with(hip.lbvh_builder())
+        assert _tree_cost(s) > cost
+
+
 @pytest.mark.parametrize("leaf_cap", [10 ** 9, 300])
 def test_leaves_of_more_than_127_primitives(leaf_cap):
     """A caller's builder may hand over leaves larger than the 7-bit count of the packed child
