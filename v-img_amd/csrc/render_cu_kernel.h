@@ -887,6 +887,8 @@ VD void cu_walk(uint32_t& n_closest, uint32_t& n_shadow) {
   uint32_t c_internal = 0, c_leaf = 0, c_prim = 0, c_sphere = 0;   // per-lane event counts of statistics launches
   uint32_t d_box = 0, d_boxl = 0, d_leaf = 0, d_leafl = 0, d_ref = 0, d_refr = 0;   // wave-uniform: passes and lanes (statistics launches)
   uint32_t t_in = 0;   // statistics launches: when this lane took its ray
+  unsigned long long d_waitc = 0, d_rayc = 0;   // ... per-lane sums (one atomic per wave and session, not one per ray: the
+  uint32_t d_waitn = 0, d_rayn = 0;             //     statistics must not be what they measure)
   unsigned long long wt = full_stats ? __builtin_readcyclecounter() : 0ull, wc0 = 0, wc1 = 0, wc2 = 0, wc3 = 0;
   auto wlap = [&](unsigned long long& acc) {
     if (full_stats) {
@@ -909,10 +911,9 @@ VD void cu_walk(uint32_t& n_closest, uint32_t& n_shadow) {
           d_ref += stat_inc, d_refr += full_stats ? got : 0u;
           if (w_slot == SLOT_IDLE && lane_rank(m_idle, lane) < got) {
             if (full_stats) {
-              __hip_atomic_fetch_add(&wrec->wait_cyc[4], static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_readcyclecounter()) - tq[e & 0x7fffu]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              __hip_atomic_fetch_add(&wrec->wait_n[4], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              t_in = static_cast<uint32_t>(__builtin_readcyclecounter());
+              d_waitc += static_cast<unsigned long long>(t_in - tq[e & 0x7fffu]), d_waitn += 1u;
             }
-            if (full_stats) t_in = static_cast<uint32_t>(__builtin_readcyclecounter());
             w_slot = e & 0x7fffu;
             w_type = (e & CU_RAY_S) ? 0u : 1u;
             w_setup = true;
@@ -1087,10 +1088,7 @@ VD void cu_walk(uint32_t& n_closest, uint32_t& n_shadow) {
       }
       if (__any(done)) {
         hand_to_vertex(complete, nw, w_slot);
-        if (full_stats && done) {
-          __hip_atomic_fetch_add(&wrec->ray_cyc, static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_readcyclecounter()) - t_in), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_fetch_add(&wrec->ray_n, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        if (full_stats && done) d_rayc += static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_readcyclecounter()) - t_in), d_rayn += 1u;
         if (done) w_slot = SLOT_IDLE;
       }
     }
@@ -1099,10 +1097,17 @@ VD void cu_walk(uint32_t& n_closest, uint32_t& n_shadow) {
   }
   if (full_stats) {
     if (lane == 0) wrec->w_cyc[0] += wc0, wrec->w_cyc[1] += wc1, wrec->w_cyc[2] += wc2, wrec->w_cyc[3] += wc3;
-    __hip_atomic_fetch_add(&wrec->internal, c_internal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_add(&wrec->leaf, c_leaf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_add(&wrec->prim, c_prim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_add(&wrec->sphere, c_sphere, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    auto wsum = [](unsigned long long v) {
+      for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+      return v;
+    };
+    const unsigned long long s_int = wsum(c_internal), s_leaf = wsum(c_leaf), s_prim = wsum(c_prim), s_sph = wsum(c_sphere);
+    const unsigned long long s_wc = wsum(d_waitc), s_wn = wsum(d_waitn), s_rc = wsum(d_rayc), s_rn = wsum(d_rayn);
+    if (lane == 0) {
+      wrec->internal += static_cast<uint32_t>(s_int), wrec->leaf += static_cast<uint32_t>(s_leaf);
+      wrec->prim += static_cast<uint32_t>(s_prim), wrec->sphere += static_cast<uint32_t>(s_sph);
+      wrec->wait_cyc[4] += s_wc, wrec->wait_n[4] += s_wn, wrec->ray_cyc += s_rc, wrec->ray_n += s_rn;
+    }
     if (lane == 0) {
       wrec->box_pass += d_box, wrec->box_lanes += d_boxl, wrec->leaf_round += d_leaf, wrec->leaf_lanes += d_leafl;
       wrec->sessions += 1, wrec->refills += d_ref, wrec->refill_rays += d_refr;
@@ -1203,9 +1208,10 @@ render_cu_kernel(const CuKArgs ka) {
       lap(5);
       if (full_stats) iter_wave++;
       if (full_stats && lane == 0) wrec->nbatch[cls] += 1, wrec->nslots[cls] += n;
-      if (full_stats && lane < n) {
-        __hip_atomic_fetch_add(&wrec->wait_cyc[cls], static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_readcyclecounter()) - tq[e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&wrec->wait_n[cls], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (full_stats) {
+        unsigned long long w = lane < n ? static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_readcyclecounter()) - tq[e]) : 0ull;
+        for (int o = 32; o; o >>= 1) w += __shfl_xor(w, o);
+        if (lane == 0) wrec->wait_cyc[cls] += w, wrec->wait_n[cls] += n;
       }
       bool all_pending = false;
       const bool by_class = A.pool_classes == 3u;
