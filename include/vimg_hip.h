@@ -205,7 +205,7 @@ int vimg_hip_build_lbvh(uint32_t n, const float* bounds6, uint32_t* num_nodes, u
  * radius 12), leaves ended by the reference builders' surface-area heuristic (up to 8 primitives,
  * include/bvh.h:17-20), and the top of the tree - the 16 384 subtrees of largest area - rebuilt
  * top-down by binned SAH (the quantity src/bvh/sweep_bvh.cpp:7-49 sweeps), all in kernels: 519 K
- * triangles in 4.7 ms of kernels + 2.9 ms of layout and download; the renderer runs within 2 % of its
+ * triangles in 4.5 ms of kernels + 2.7 ms of layout and download; the renderer runs within 3 % of its
  * rate on the host's sweep-SAH tree.  Same buffers, same layout, same hook as
  * vimg_hip_build_lbvh. */
 int vimg_hip_build_ploc(uint32_t n, const float* bounds6, uint32_t* num_nodes, uint32_t* max_depth,

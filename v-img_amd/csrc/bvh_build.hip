@@ -58,12 +58,11 @@ __host__ __device__ __forceinline__ float unordered(uint32_t u) {
 
 __global__ void lb_centre_bounds(const float* __restrict__ bounds, uint32_t n, uint32_t* __restrict__ mm) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float* b = bounds + size_t(i) * 6;
+  const float* b = bounds + size_t(i < n ? i : n - 1u) * 6;
   for (int a = 0; a < 3; ++a) {
-    const uint32_t c = ordered((b[a] + b[3 + a]) * 0.5f);
-    atomicMin(&mm[a], c);
-    atomicMax(&mm[3 + a], c);
+    uint32_t lo = ordered((b[a] + b[3 + a]) * 0.5f), hi = lo;
+    for (int o = 32; o; o >>= 1) lo = min(lo, __shfl_xor(lo, o)), hi = max(hi, __shfl_xor(hi, o));   // one pair of atomics per wave
+    if ((threadIdx.x & 63u) == 0u) atomicMin(&mm[a], lo), atomicMax(&mm[3 + a], hi);
   }
 }
 
