@@ -479,9 +479,18 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan,
   }
 
   pv_lap(1);
+  // A class batch does not change the path's running result after this point (under the material integrator
+  // it is ASSIGNED below and stored again): it leaves the registers here, not at the end of the stage.
+  if constexpr (!finisher_batch) {
+    if (have && !mirror) {
+      VIMG_GLOBAL uint32_t* rw = reinterpret_cast<VIMG_GLOBAL uint32_t*>(cold + (slot * SC4_MAIN + SC_RESULT));
+      rw[0] = fu(result.x), rw[1] = fu(result.y), rw[2] = fu(result.z);
+    }
+  }
   // ---- the next rays of a vertex
   bool has_s = false, has_r = false;
   bool early = false, pushed_r = false;   // EARLY launches: this lane queues its rays before the end of the stage / has queued its path ray
+  bool rec_written = false;               // this lane's rays are in the slot's record already (a vertex of the mis integrator)
   f3 shadow_d{0.f, 0.f, 1.f}, nee_contrib{0.f, 0.f, 0.f};
   float shadow_max_t = 0.f;
   // (a finisher batch never holds a vertex to shade: the walk sends every hit on a non-emitter to
@@ -585,33 +594,33 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan,
     }
     early = early_on && at_vertex && !mirror;
     pushed_r = early && sc.valid;
-    if (early_on) {
-      if (early) {
-        // origin of both rays, the path ray and the flag word the walkers will OR into (nobody else
-        // touches it yet): written before the first ray is queued
-        wr(CR_ORG, slot, v4u{fu(hit.p.x), fu(hit.p.y), fu(hit.p.z), 0u});
-        wr(CR_DIR, slot, v4u{fu(sc.wo.x), fu(sc.wo.y), fu(sc.wo.z),
-                             (sc.valid ? CF_HAS_R : 0u) | (non_specular_bounce ? CF_NONSPEC : 0u) | (bounce << CF_BOUNCE_SHIFT)});
-        if (full_stats) tq[slot] = static_cast<uint32_t>(__builtin_readcyclecounter());
-      }
-      push_rays(false, pushed_r, slot);
+    // The rays go into the slot's record as soon as they are known - origin, path ray, below the shadow
+    // ray - whenever they are queued: the evaluations take their directions from there, and ten
+    // registers are free while they run.  EARLY launches: with the flag word the walkers will OR into
+    // (nobody else touches it yet), before the first ray is queued; else the word follows at the end.
+    rec_written = at_vertex && !mirror;
+    if (rec_written) {
+      wr(CR_ORG, slot, v4u{fu(hit.p.x), fu(hit.p.y), fu(hit.p.z), 0u});
+      wr(CR_DIR, slot, v4u{fu(sc.wo.x), fu(sc.wo.y), fu(sc.wo.z),
+                           (sc.valid ? CF_HAS_R : 0u) | (non_specular_bounce ? CF_NONSPEC : 0u) | (bounce << CF_BOUNCE_SHIFT)});
+      if (full_stats && early) tq[slot] = static_cast<uint32_t>(__builtin_readcyclecounter());
     }
+    if (early_on) push_rays(false, pushed_r, slot);
     pv_lap(3);
     if (at_vertex && mat_type != VIMG_MAT_DIELECTRIC) {
       lights_sample<TEX>(g, hit.p, rng_l, light_col, li);
       nee = (li.pdf != 0.f);
     }
-    if (early_on) {
-      if (early && nee) {
-        // the shadow ray and its reach beside a record whose other words a walker may be reading: one dword
-        recw[(CR_ORG * P + slot) * 4u + 3u] = fu(li.dist - 0.0001f);
-        wr(CR_SHD, slot, v4u{fu(li.wi.x), fu(li.wi.y), fu(li.wi.z), hops});
-        __hip_atomic_fetch_or(flag_word(slot), CF_HAS_S, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      } else if (early && full_stats) {
-        recw[(CR_SHD * P + slot) * 4u + 3u] = hops;
-      }
-      push_rays(early && nee, false, slot);
+    if (rec_written && nee) {
+      // the shadow ray and its reach (the reference's absolute epsilon, quirk Q15) beside a record whose
+      // other words a walker may be reading: one dword
+      recw[(CR_ORG * P + slot) * 4u + 3u] = fu(li.dist - 0.0001f);
+      wr(CR_SHD, slot, v4u{fu(li.wi.x), fu(li.wi.y), fu(li.wi.z), hops});
+      if (early) __hip_atomic_fetch_or(flag_word(slot), CF_HAS_S, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else if (rec_written && full_stats) {
+      recw[(CR_SHD * P + slot) * 4u + 3u] = hops;
     }
+    if (early_on) push_rays(early && nee, false, slot);
     pv_lap(2);
     if (at_vertex) {
       // both BSDF evaluations happen before either ray's result is looked at: the evaluation towards
@@ -626,7 +635,8 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan,
         f3 f{0.f, 0.f, 0.f};
         float pdf = 0.f;
         if (run) {
-          const f3 wo = second ? sc.wo : li.wi;
+          const v4u w4 = rd(second ? CR_DIR : CR_SHD, slot);   // (sc.wo / li.wi, from the slot's record)
+          const f3 wo{uf(w4.x), uf(w4.y), uf(w4.z)};
           const RayCone c = second ? cone : nee_cone;
           const bool reg = second ? non_specular_bounce : reg_before;
           eval_pdf_pair<TEX, MT>(g, hit, ray_d, wo, c, reg, f, pdf);
@@ -658,10 +668,6 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan,
       }
       has_s = nee;
       has_r = sc.valid;
-      shadow_d = li.wi;
-      shadow_max_t = li.dist - 0.0001f;   // absolute epsilon of the reference (quirk Q15)
-      ray_o = hit.p;
-      ray_d = sc.wo;
       primary = false;
       if (!has_s && !has_r) finish = true;
     }
@@ -816,15 +822,27 @@ VD void cu_vertex(uint32_t n, uint32_t slot, bool& all_pending, uint32_t& n_nan,
                                   : ((primary ? CF_PRIMARY : 0u) | (non_specular_bounce ? CF_NONSPEC : 0u) |
                                      (has_s ? CF_HAS_S : 0u) | (has_r ? CF_HAS_R : 0u) | CF_DONE_V | (bounce << CF_BOUNCE_SHIFT));
       if (pending) has_s = false, has_r = false, smp = claim;
-      wr(CR_ORG, slot, v4u{fu(ray_o.x), fu(ray_o.y), fu(ray_o.z), fu(shadow_max_t)});
-      wr(CR_DIR, slot, v4u{fu(ray_d.x), fu(ray_d.y), fu(ray_d.z), nf});
-      if (has_s) wr(CR_SHD, slot, v4u{fu(shadow_d.x), fu(shadow_d.y), fu(shadow_d.z), hops});
-      else if (full_stats) recw[(CR_SHD * P + slot) * 4u + 3u] = hops;
+      if (rec_written) {
+        *flag_word(slot) = nf;
+      } else {
+        wr(CR_ORG, slot, v4u{fu(ray_o.x), fu(ray_o.y), fu(ray_o.z), fu(shadow_max_t)});
+        wr(CR_DIR, slot, v4u{fu(ray_d.x), fu(ray_d.y), fu(ray_d.z), nf});
+        if (has_s) wr(CR_SHD, slot, v4u{fu(shadow_d.x), fu(shadow_d.y), fu(shadow_d.z), hops});
+        else if (full_stats) recw[(CR_SHD * P + slot) * 4u + 3u] = hops;
+      }
     }
     cwr(SC_THROUGHPUT, slot, v4u{fu(throughput.x), fu(throughput.y), fu(throughput.z), fu(eta_scale)});
-    cwr(SC_RESULT, slot, v4u{fu(result.x), fu(result.y), fu(result.z), fu(prev_pdf)});
+    if constexpr (finisher_batch) {
+      cwr(SC_RESULT, slot, v4u{fu(result.x), fu(result.y), fu(result.z), fu(prev_pdf)});
+      cwr(SC4_RNG, slot, v4u{static_cast<uint32_t>(rng.s), static_cast<uint32_t>(rng.s >> 32), px | (py << 16), smp});
+    } else {
+      // (the result went out above; the pixel and the sample count of the record are the finisher's)
+      VIMG_GLOBAL uint32_t* rw = reinterpret_cast<VIMG_GLOBAL uint32_t*>(cold + (slot * SC4_MAIN + SC_RESULT));
+      rw[3] = fu(prev_pdf);
+      if (material_mode) rw[0] = fu(result.x), rw[1] = fu(result.y), rw[2] = fu(result.z);
+      *reinterpret_cast<VIMG_GLOBAL v2u*>(cold + (slot * SC4_MAIN + SC4_RNG)) = v2u{static_cast<uint32_t>(rng.s), static_cast<uint32_t>(rng.s >> 32)};
+    }
     if (has_s) cwr(SC_NEE, slot, v4u{fu(nee_contrib.x), fu(nee_contrib.y), fu(nee_contrib.z), 0u});
-    cwr(SC4_RNG, slot, v4u{static_cast<uint32_t>(rng.s), static_cast<uint32_t>(rng.s >> 32), px | (py << 16), smp});
     if (finisher_batch) cold_acc[slot] = v4u{fu(acc.x), fu(acc.y), fu(acc.z), item};
     if constexpr (TEX) cold_cone[slot] = v4u{fu(cone.cone_width), fu(cone.spread_angle), 0u, 0u};
   }
