@@ -314,13 +314,6 @@ def main():
                     gathered.copy_(host)
                 dev.assemble_shards(gathered, n, stride, out=frame, stream=stream)
 
-        # event counts of one step (deterministic: same seeds every step); not timed
-        _, st = dev.render(params, out=slab, stats=True, stream=stream)
-        local_pixels = st.paths // args.spp
-        local_bytes = algorithmic_bytes(st, local_pixels)
-        counts = torch.tensor([st.rays, st.paths, local_bytes], dtype=torch.float64, device=red_dev)
-        if n > 1:
-            dist.all_reduce(counts)
         for _ in range(warmup):
             step()
         events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -337,6 +330,15 @@ def main():
         elapsed = time.perf_counter() - t0
         dev.check()     # a frame the kernel's watchdog gave up is an error, not a measurement
         kernel_ms = sum(a.elapsed_time(b) for a, b in events) / steps
+        # event counts of one step (deterministic: same seeds every step); not timed, and AFTER the timed
+        # launches: the statistics build uses scratch, and rocprofv3's dispatch records show a queue's
+        # scratch on every later dispatch (the timed kernel's own record: Scratch_Size 0)
+        _, st = dev.render(params, out=slab, stats=True, stream=stream)
+        local_pixels = st.paths // args.spp
+        local_bytes = algorithmic_bytes(st, local_pixels)
+        counts = torch.tensor([st.rays, st.paths, local_bytes], dtype=torch.float64, device=red_dev)
+        if n > 1:
+            dist.all_reduce(counts)
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=red_dev)
         if n > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

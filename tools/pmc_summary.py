@@ -46,8 +46,8 @@ n = max(launches.values()) if launches else 0
 if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None and n:
     d["hbm_side_bytes_per_launch"] = (g("FETCH_SIZE") * 2 + g("WRITE_SIZE")) * 1024 / n
 out = {"dispatch": meta, "launches_per_pass": n, "counters": agg, "derived": d,
-       "note": "each counter is summed over the render-kernel dispatches of its pass (launches_per_pass of them: a stats "
-               "launch and the timed ones); FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md, HBM)"}
+       "note": "each counter is summed over the dispatches of the timed render kernel in its pass (launches_per_pass of them; the "
+               "statistics launch that follows them runs another build and is not counted); FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md, HBM)"}
 if len(sys.argv) > 2:
     try:
         out["run"] = json.loads([l for l in open(sys.argv[2]) if l.startswith("{")][-1])
