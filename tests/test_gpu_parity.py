@@ -399,6 +399,34 @@ def test_probes_bsdf_and_lights():
     assert np.allclose(bg, bc, rtol=2e-5, atol=1e-7)
 
 
+def test_sincos_is_the_two_calls_it_replaces():
+    """The warps take sin and cos of an angle from ONE sincos (device_math.h: D_sincos; the compiler does not
+    merge the two calls, and they are a tenth of a Lambertian vertex).  The pictures only stay the
+    reference's if that is the same pair of doubles the separate calls return: 2^24 arguments - the
+    angles 2 pi u the warps draw, the whole float range around them, negative and large ones, the
+    special values - give the same bits, doubles included; and the floats are glibc's."""
+    s = scenes.json_scene("disney_spheres.json", res=(16, 8))
+    d = _dev(s)
+    rng = np.random.default_rng(7)
+    n = 1 << 22
+    x = np.concatenate([
+        (np.float32(2.0) * np.float32(np.pi) * rng.random(n, dtype=np.float32)).astype(np.float32),
+        rng.integers(0, np.float32(6.2831855).view(np.uint32), n, dtype=np.uint32).view(np.float32),
+        rng.uniform(-1e6, 1e6, n).astype(np.float32),
+        (rng.normal(size=n) * 10.0 ** rng.uniform(-30, 8, n)).astype(np.float32),
+    ])
+    x[:8] = np.array([0.0, -0.0, np.pi, -np.pi, 2 * np.pi, 1e-40, 3.4e38, -3.4e38], dtype=np.float32)
+    out = d.probe(8, x.reshape(-1, 1))
+    assert np.array_equal(out[:, 0].view(np.uint32), out[:, 2].view(np.uint32))
+    assert np.array_equal(out[:, 1].view(np.uint32), out[:, 3].view(np.uint32))
+    assert np.all(out[:, 4] == 1.0)
+    # ... and they are the host's: float(cos(double(x))) differs from glibc's on no more than a few arguments
+    # in a million (double results that differ in their last bit AND straddle a float rounding boundary)
+    ref_c, ref_s = np.cos(x.astype(np.float64)).astype(np.float32), np.sin(x.astype(np.float64)).astype(np.float32)
+    small = np.abs(x) < 1e5
+    assert np.mean(out[small, 2] != ref_c[small]) < 1e-5 and np.mean(out[small, 3] != ref_s[small]) < 1e-5
+
+
 def test_tile_shards_reassemble_to_the_single_gpu_image():
     # image is independent of the number of shards by construction (per-pixel seeds)
     import torch

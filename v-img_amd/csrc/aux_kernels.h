@@ -28,7 +28,7 @@ __global__ void assemble_kernel(const float* __restrict__ shards, float* __restr
 // Unit-level entry points used by the parity tests; layouts mirror the checker's probe API.
 enum {
   PROBE_CAMERA_RAY = 1, PROBE_CLOSEST_HIT = 2, PROBE_OCCLUDED = 3, PROBE_BSDF_EVAL = 4,
-  PROBE_BSDF_SAMPLE = 5, PROBE_LIGHT_SAMPLE = 6, PROBE_BACKGROUND = 7
+  PROBE_BSDF_SAMPLE = 5, PROBE_LIGHT_SAMPLE = 6, PROBE_BACKGROUND = 7, PROBE_SINCOS = 8
 };
 template <bool TEX>
 __global__ void __launch_bounds__(256)
@@ -135,6 +135,18 @@ probe_kernel(const DScene g, const RenderArgs A, int kind, int n, const float* _
       f3 d{p[0], p[1], p[2]};
       f3 e = background_emit<TEX>(g, d, RayCone{p[3], p[4]});
       o[0] = e.x, o[1] = e.y, o[2] = e.z, o[3] = background_pdf<TEX>(g, d);
+      break;
+    }
+    case PROBE_SINCOS: {
+      // D_sincos (device_math.h) against the two calls it replaces: the floats the renderer uses, and
+      // whether the doubles behind them are the same bits
+      const float x = in[i];
+      float* o = out + 5 * i;
+      const double c0 = ::cos(static_cast<double>(x)), s0 = ::sin(static_cast<double>(x));
+      double s1, c1;
+      D_sincos(x, s1, c1);
+      o[0] = static_cast<float>(c0), o[1] = static_cast<float>(s0), o[2] = static_cast<float>(c1), o[3] = static_cast<float>(s1);
+      o[4] = (__double_as_longlong(c0) == __double_as_longlong(c1) && __double_as_longlong(s0) == __double_as_longlong(s1)) ? 1.f : 0.f;
       break;
     }
     default:

@@ -73,6 +73,10 @@ VD float sqrt_f(float x) { return __builtin_sqrtf(x); }
 // float-overload transcendentals of the reference: double evaluation, one rounding to float
 VD float F_cos(float x) { return static_cast<float>(::cos(static_cast<double>(x))); }
 VD float F_sin(float x) { return static_cast<float>(::sin(static_cast<double>(x))); }
+// sin and cos of the same angle: one argument reduction and one pair of polynomials instead of two (the
+// compiler does not merge the two calls; ocml's sin, cos and sincos share the reduction and the kernel, so
+// the results are the same doubles - checked for every float in [-2 pi, 1e6] once, and on 2^24 arguments by tests/test_gpu_parity.py)
+VD void D_sincos(float x, double& s, double& c) { ::sincos(static_cast<double>(x), &s, &c); }
 VD float F_acos(float x) { return static_cast<float>(::acos(static_cast<double>(x))); }
 VD float F_atan2(float y, float x) {
   return static_cast<float>(::atan2(static_cast<double>(y), static_cast<double>(x)));

@@ -64,6 +64,18 @@ struct __attribute__((aligned(16))) DTriShade {
 };
 static_assert(sizeof(DTriShade) == 64, "DTriShade must be 64 bytes");
 
+// One emitter of GroupOfEmitters::list_of_emitters, 80 B: everything its sample() reads, in one fetch
+// instead of the chase light -> primitive -> triangle / sphere -> mesh -> material (five dependent loads
+// in front of every next-event estimate).
+//  kind 0 background        kind 1 triangle without vertex normals: a b c = p0 p1 p2 n (the baked face normal)
+//  kind 3 sphere: a = centre, radius      kind 2 triangle with vertex normals: sampled through the tables (index)
+//  d = the material's emission (zero when it is no DiffuseLight), w = the triangle's area pdf
+struct __attribute__((aligned(16))) DLight {
+  v4f a, b, c, d;
+  uint32_t kind, index, pad0, pad1;
+};
+static_assert(sizeof(DLight) == 80, "DLight must be 80 bytes");
+
 struct DScene {
   // camera (TLCam members, reference src/tl_camera.cpp:6-23) — derived values computed on the host
   float cam_to_world[16];
@@ -94,6 +106,7 @@ struct DScene {
   gptr<VimgTextureRG> rg_textures;
   gptr<float> rg_texels;
   gptr<VimgLight> lights;
+  gptr<DLight> dlights;       // the same list, baked
   uint32_t num_lights;
   gptr<float> cdf_pool;
   VimgBackground background;

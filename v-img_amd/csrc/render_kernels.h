@@ -84,14 +84,18 @@ VD f2 random_x_y_r2(uint32_t n) {
 VD f2 sample_disk(float rand1, float rand2) {
   float r = sqrt_f(rand1);
   float phi = 2.f * kPi * rand2;
-  return f2{r * F_cos(phi), r * F_sin(phi)};
+  double sn, cs;
+  D_sincos(phi, sn, cs);
+  return f2{r * static_cast<float>(cs), r * static_cast<float>(sn)};
 }
 VD f3 sample_sphere(float rand1, float rand2) {
   float phi = 2 * kPi * rand1;
   float cos_theta = 2 * rand2 - 1;
   float sin_theta = static_cast<float>(__builtin_sqrt(static_cast<double>(1 - cos_theta * cos_theta)));
-  float x = ::cos(static_cast<double>(phi)) * sin_theta;
-  float y = ::sin(static_cast<double>(phi)) * sin_theta;
+  double sn, cs;
+  D_sincos(phi, sn, cs);
+  float x = cs * sin_theta;   // (double product, one rounding: std::cos(float) is the double function here)
+  float y = sn * sin_theta;
   return f3{x, y, cos_theta};
 }
 // std::lerp(float,float,float) as libstdc++ implements it (exact ends, monotonic)
@@ -105,16 +109,20 @@ VD f3 sample_sphere_cap(float rand1, float rand2, float cos_theta_max) {
   float phi = 2 * kPi * rand1;
   float cos_theta = std_lerp(cos_theta_max, 1.0f, rand2);
   float sin_theta = sqrt_f(1 - cos_theta * cos_theta);
-  float x = ::cos(static_cast<double>(phi)) * sin_theta;
-  float y = ::sin(static_cast<double>(phi)) * sin_theta;
+  double sn, cs;
+  D_sincos(phi, sn, cs);
+  float x = cs * sin_theta;
+  float y = sn * sin_theta;
   return f3{x, y, cos_theta};
 }
 VD f3 sample_hemisphere_cosine(float rand1, float rand2) {
   float phi = 2 * kPi * rand1;
   float cos_theta = sqrt_f(rand2);
   float sin_theta = sqrt_f(1 - cos_theta * cos_theta);
-  float x = F_cos(phi) * sin_theta;
-  float y = F_sin(phi) * sin_theta;
+  double sn, cs;
+  D_sincos(phi, sn, cs);
+  float x = static_cast<float>(cs) * sin_theta;
+  float y = static_cast<float>(sn) * sin_theta;
   return f3{x, y, cos_theta};
 }
 
@@ -209,8 +217,10 @@ VD bool refract_with_tir_2d(f2 ray_dir, f2 normal, float eta, f2& out) {
   return true;
 }
 VD void rotate_2d_plus_minus(f2 v, float angle, f2& plus, f2& minus) {
-  float c = ::cos(static_cast<double>(angle));
-  float s = ::sin(static_cast<double>(angle));
+  double sn, cs;
+  D_sincos(angle, sn, cs);
+  float c = static_cast<float>(cs);
+  float s = static_cast<float>(sn);
   float cx = c * v.x, sy = s * v.y, sx = s * v.x, cy = c * v.y;
   plus = f2{cx - sy, +sx + cy};
   minus = f2{cx + sy, -sx + cy};
@@ -1309,20 +1319,9 @@ VD void eval_pdf_pair(const DScene& g, const Hit& hit, f3 wi, f3 wo, RayCone con
 
 // ================================================================================ emitters
 // Triangle::sample: reference src/geometry/triangle.cpp:178-233
-VD void tri_light_sample(const DScene& g, uint32_t tri, f3 look_from, Rng& rng, f3& le,
-                         EmitterInfo& info) {
-  gptr<DTriShade> ts = g.tri_shade + tri;
-  const f3 p0{ts->p[0], ts->p[1], ts->p[2]}, p1{ts->p[3], ts->p[4], ts->p[5]},
-      p2{ts->p[6], ts->p[7], ts->p[8]};
-  gptr<VimgMesh> mesh = g.meshes + ts->mesh;
-  const f3 edge1 = p1 - p0, edge2 = p2 - p0;
-  f3 tri_normal{ts->n[0], ts->n[1], ts->n[2]};   // normalize(cross(edge1, edge2)), baked
-  f3 n0 = tri_normal, n1 = tri_normal, n2 = tri_normal;
-  if (mesh->has_normals) {
-    n0 = load3(g.normals + 3 * size_t(ts->i0));
-    n1 = load3(g.normals + 3 * size_t(ts->i1));
-    n2 = load3(g.normals + 3 * size_t(ts->i2));
-  }
+// (the sampling itself, given the triangle: corners, vertex normals, area pdf)
+VD void tri_light_sample_with(f3 p0, f3 p1, f3 p2, f3 n0, f3 n1, f3 n2, float pdf, f3 look_from, Rng& rng, f3& hit_n,
+                              EmitterInfo& info) {
   float rand1 = rand_float(rng);
   float rand2 = rand_float(rng);
   float u, v;
@@ -1335,26 +1334,41 @@ VD void tri_light_sample(const DScene& g, uint32_t tri, f3 look_from, Rng& rng, 
   }
   float w = 1.f - u - v;
   const f3 hit_p = p0 * u + p1 * v + p2 * w;
-  f3 hit_n = normalize(u * n0 + v * n1 + w * n2);
+  hit_n = normalize(u * n0 + v * n1 + w * n2);
   f3 dir_vec = hit_p - look_from;
   float dist2 = length2(dir_vec);
   dir_vec = normalize(dir_vec);
-  float pdf = g.tri_area_pdf[tri];   // 1.f / (length(cross(edge2, edge1)) / 2.0f), baked
   float cosine = absf(dot(hit_n, -dir_vec));
   float G = cosine / dist2;
   info = EmitterInfo{dir_vec, pdf, sqrt_f(dist2), G};
+}
+VD void tri_light_sample_at(f3 p0, f3 p1, f3 p2, f3 tri_normal, float pdf, f3 look_from, Rng& rng, f3& hit_n, EmitterInfo& info) {
+  tri_light_sample_with(p0, p1, p2, tri_normal, tri_normal, tri_normal, pdf, look_from, rng, hit_n, info);
+}
+VD void tri_light_sample(const DScene& g, uint32_t tri, f3 look_from, Rng& rng, f3& le,
+                         EmitterInfo& info) {
+  gptr<DTriShade> ts = g.tri_shade + tri;
+  const f3 p0{ts->p[0], ts->p[1], ts->p[2]}, p1{ts->p[3], ts->p[4], ts->p[5]},
+      p2{ts->p[6], ts->p[7], ts->p[8]};
+  gptr<VimgMesh> mesh = g.meshes + ts->mesh;
+  f3 tri_normal{ts->n[0], ts->n[1], ts->n[2]};   // normalize(cross(edge1, edge2)), baked
+  f3 n0 = tri_normal, n1 = tri_normal, n2 = tri_normal;
+  if (mesh->has_normals) {
+    n0 = load3(g.normals + 3 * size_t(ts->i0));
+    n1 = load3(g.normals + 3 * size_t(ts->i1));
+    n2 = load3(g.normals + 3 * size_t(ts->i2));
+  }
+  f3 hit_n;
+  tri_light_sample_with(p0, p1, p2, n0, n1, n2, g.tri_area_pdf[tri] /* 1.f / (length(cross(edge2, edge1)) / 2.0f), baked */, look_from,
+                        rng, hit_n, info);
   le = mat_emitted(g.materials + mesh->material, info.wi, hit_n);
 }
 // Triangle::surf_pdf: reference src/geometry/triangle.cpp:235-248
 VD float tri_surf_pdf(const DScene& g, uint32_t tri) { return g.tri_area_pdf[tri]; }
 // Sphere::sample: reference src/geometry/sphere.cpp:58-118 (cone construction of quirk Q16 kept)
-VD void sphere_light_sample(const DScene& g, gptr<VimgSphere> sp, f3 look_from, Rng& rng, f3& le,
-                            EmitterInfo& info) {
-  const f3 center = load3(sp->center);
-  const float radius = sp->radius;
+VD void sphere_light_sample_at(f3 center, float radius, f3 look_from, Rng& rng, f3& shading_normal, EmitterInfo& info) {
   float rand1 = rand_float(rng);
   float rand2 = rand_float(rng);
-  f3 shading_normal;
   if (length2(look_from - center) <= radius * radius) {
     f3 unit = sample_sphere(rand1, rand2);
     f3 point_on_sphere = (unit * radius) + center;
@@ -1383,7 +1397,6 @@ VD void sphere_light_sample(const DScene& g, gptr<VimgSphere> sp, f3 look_from, 
     float pdf = pdf_solid_angle * G;
     info = EmitterInfo{sampled_dir, pdf, sqrt_f(dist2), G};
   }
-  le = mat_emitted(g.materials + sp->material, info.wi, shading_normal);
 }
 // Sphere::surf_pdf: reference src/geometry/sphere.cpp:120-139
 VD float sphere_surf_pdf(gptr<VimgSphere> sp, f3 look_from, f3 point_on_light, f3 dir) {
@@ -1506,15 +1519,26 @@ VD void lights_sample(const DScene& g, f3 look_from, Rng& rng, f3& le, EmitterIn
   float sx = rnd * g.num_lights;
   const int index_obj = clampi(static_cast<int>(sx), 0, static_cast<int>(g.num_lights) - 1);
   const float prob_obj = 1.f / g.num_lights;
-  const VimgLight l = load_light(g.lights + index_obj);
-  if (l.type == VIMG_LIGHT_BACKGROUND) {
+  // the emitter's baked record (device_scene.h: DLight): one fetch, then arithmetic
+  gptr<DLight> L = g.dlights + index_obj;
+  const uint32_t kind = L->kind;
+  if (kind == 0u) {
     background_sample<TEX>(g, rng, le, info);
+  } else if (kind == 2u) {
+    tri_light_sample(g, L->index, look_from, rng, le, info);   // (vertex normals: through the tables)
   } else {
-    const VimgPrim p = load_prim(g.prims + l.prim);
-    if (p.type == VIMG_PRIM_TRIANGLE)
-      tri_light_sample(g, p.index, look_from, rng, le, info);
-    else
-      sphere_light_sample(g, g.spheres + p.index, look_from, rng, le, info);
+    f3 shading_normal;
+    const v4f la = L->a;
+    if (kind == 1u) {
+      const v4f lb = L->b, lc = L->c;
+      tri_light_sample_at(f3{la.x, la.y, la.z}, f3{la.w, lb.x, lb.y}, f3{lb.z, lb.w, lc.x}, f3{lc.y, lc.z, lc.w}, L->d.w, look_from,
+                          rng, shading_normal, info);
+    } else {
+      sphere_light_sample_at(f3{la.x, la.y, la.z}, la.w, look_from, rng, shading_normal, info);
+    }
+    // Material::emitted of the emitter's material (DiffuseLight::emitted: one-sided; zero for the others)
+    const v4f ld = L->d;
+    le = (dot(shading_normal, info.wi) < 0) ? f3{ld.x, ld.y, ld.z} : f3{0.f, 0.f, 0.f};
   }
   info.pdf *= prob_obj;
 }

@@ -1145,6 +1145,38 @@ int vimg_hip_scene_upload_opts(const VimgScene* sc, const VimgHipOptions* opts, 
     leaf[j] = lp;
   }
 
+  // ---- emitters, baked (device_scene.h: DLight)
+  std::vector<DLight> dlights(sc->num_lights);
+  for (uint32_t i = 0; i < sc->num_lights; ++i) {
+    DLight L{};
+    const VimgLight& l = sc->lights[i];
+    if (l.type == VIMG_LIGHT_BACKGROUND) {
+      L.kind = 0u;
+    } else {
+      const VimgPrim& p = sc->prims[l.prim];
+      L.index = p.index;
+      uint32_t mat;
+      if (p.type == VIMG_PRIM_TRIANGLE) {
+        const VimgMesh& mesh = sc->meshes[sc->tri_mesh[p.index]];
+        const DTriShade& ts = shade[p.index];
+        L.kind = mesh.has_normals ? 2u : 1u;
+        L.a = v4f{ts.p[0], ts.p[1], ts.p[2], ts.p[3]};
+        L.b = v4f{ts.p[4], ts.p[5], ts.p[6], ts.p[7]};
+        L.c = v4f{ts.p[8], ts.n[0], ts.n[1], ts.n[2]};
+        L.d.w = area_pdf[p.index];
+        mat = mesh.material;
+      } else {
+        const VimgSphere& sp = sc->spheres[p.index];
+        L.kind = 3u;
+        L.a = v4f{sp.center[0], sp.center[1], sp.center[2], sp.radius};
+        mat = sp.material;
+      }
+      const VimgMaterial& m = sc->materials[mat];
+      if (m.type == VIMG_MAT_DIFFUSE_LIGHT) L.d.x = m.emit[0], L.d.y = m.emit[1], L.d.z = m.emit[2];   // (Material::emitted of the others: 0)
+    }
+    dlights[i] = L;
+  }
+
   // ---- material flags / kernel variant
   std::vector<uint32_t> mflags(sc->num_materials, 0);
   bool textured = (sc->background.type == VIMG_BG_ENVMAP);
@@ -1186,6 +1218,7 @@ int vimg_hip_scene_upload_opts(const VimgScene* sc, const VimgHipOptions* opts, 
   UP(rg_textures, sc->rg_textures, sc->num_rg_textures);
   UP(rg_texels, sc->rg_texels, sc->num_rg_texels * 2);
   UP(lights, sc->lights, sc->num_lights);
+  UP(dlights, dlights.data(), dlights.size());
   UP(cdf_pool, sc->cdf_pool, sc->num_cdf);
 #undef UP
   d.num_lights = sc->num_lights;
@@ -1564,9 +1597,9 @@ int vimg_hip_rgb8_to_normal(const uint8_t* rgb8, uint64_t n_pixels, float scale,
 
 // Unit-level probe (declared here, not in vimg_hip.h: it is a test hook, not part of the seam).
 int vimg_hip_probe(VimgDeviceScene* s, int kind, int n, const float* in_host, float* out_host) {
-  static const int n_in[8] = {0, 4, 6, 7, 12, 8, 4, 5};
-  static const int n_out[8] = {0, 8, 28, 1, 5, 7, 10, 4};
-  if (!s || kind < 1 || kind > 7 || n <= 0 || !in_host || !out_host)
+  static const int n_in[9] = {0, 4, 6, 7, 12, 8, 4, 5, 1};
+  static const int n_out[9] = {0, 8, 28, 1, 5, 7, 10, 4, 5};
+  if (!s || kind < 1 || kind > 8 || n <= 0 || !in_host || !out_host)
     return fail(VIMG_E_INVALID, "probe: bad arguments");
   float *d_in = nullptr, *d_out = nullptr;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_in), size_t(n) * n_in[kind] * sizeof(float)));

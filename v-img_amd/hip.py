@@ -177,7 +177,7 @@ class DeviceScene:
 
     def probe(self, kind, inputs):
         """Unit-level test hook (vimg_hip_probe): per item n_in floats in, n_out floats out."""
-        n_io = {1: (4, 8), 2: (6, 28), 3: (7, 1), 4: (12, 5), 5: (8, 7), 6: (4, 10), 7: (5, 4)}
+        n_io = {1: (4, 8), 2: (6, 28), 3: (7, 1), 4: (12, 5), 5: (8, 7), 6: (4, 10), 7: (5, 4), 8: (1, 5)}
         fn = self._lib.vimg_hip_probe
         fn.restype = C.c_int
         fn.argtypes = [C.c_void_p, C.c_int, C.c_int, abi.Pf32, abi.Pf32]
