@@ -37,11 +37,13 @@ p = s.default_params(samples=spp, tile_rank=tr, tile_world=tw)
 w, h = s.resolution
 n_out = w * h if tw == 1 else d.shard_pixels(p)
 out = torch.empty((n_out, 3), dtype=torch.float32, device="cuda")
-if os.environ.get("VIMG_HIP_DIAG"):
-    d.render(p, out=out)          # (diagnostics are printed by the first statistics launch)
+diag = bool(os.environ.get("VIMG_HIP_DIAG"))
+if diag:
+    _, st = d.render(p, out=out)  # (a diagnostics run: the statistics launch prints them; the times below then carry the +1 %)
 d.time_renders(p, out, 1)        # warm-up (first launch: pool allocation, cold instruction cache)
 ms = d.time_renders(p, out, steps)
-_, st = d.render(p, out=out)      # event counts AFTER the timed launches: the statistics build uses scratch, and a queue
+if not diag:
+    _, st = d.render(p, out=out)  # event counts AFTER the timed launches: the statistics build uses scratch, and a queue
                                   # that has once dispatched a kernel with scratch sets it up for every later dispatch (+1 %)
 sec = float(ms.min()) * 1e-3
 print(json.dumps({"scheduler": sched, "kernel": d.kernel_for(p), "scene": which, "res": [w, h], "spp": spp, "tile_world": tw,
