@@ -663,9 +663,13 @@ extern "C" int vimg_hip_build_ploc(uint32_t n, const float* bounds6, uint32_t* n
   LB_TRY(hipMalloc(&d_parent.p, size_t(2) * n * 4));
   LB_TRY(hipMalloc(&d_firstpos.p, size_t(2) * n * 4));
   const PlocRec rec{d_nprims.as<uint32_t>(), d_cost.as<float>(), d_as_leaf.as<uint32_t>(), d_parent.as<uint32_t>(), d_firstpos.as<uint32_t>()};
-  hipEvent_t ev0, ev1;
-  LB_TRY(hipEventCreate(&ev0));
-  LB_TRY(hipEventCreate(&ev1));
+  struct Ev {   // (destroyed on every way out)
+    hipEvent_t e = nullptr;
+    ~Ev() { if (e) (void)hipEventDestroy(e); }
+  } e0, e1;
+  LB_TRY(hipEventCreate(&e0.e));
+  LB_TRY(hipEventCreate(&e1.e));
+  const hipEvent_t ev0 = e0.e, ev1 = e1.e;
   LB_TRY(hipMemcpy(d_bounds.p, bounds6, size_t(n) * 6 * sizeof(float), hipMemcpyHostToDevice));
   const uint32_t mm_init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
   LB_TRY(hipMemcpy(d_mm.p, mm_init, sizeof(mm_init), hipMemcpyHostToDevice));
@@ -766,7 +770,6 @@ extern "C" int vimg_hip_build_ploc(uint32_t n, const float* bounds6, uint32_t* n
   LB_TRY(hipDeviceSynchronize());
   float gpu_ms = 0.f;
   (void)hipEventElapsedTime(&gpu_ms, ev0, ev1);
-  (void)hipEventDestroy(ev0), (void)hipEventDestroy(ev1);
   const auto t_gpu = std::chrono::steady_clock::now();
   const EmitTree tree{d_left.as<uint32_t>(), d_right.as<uint32_t>(), d_box.as<float>(), d_nprims.as<uint32_t>(), d_as_leaf.as<uint32_t>(),
                       d_keys2.as<unsigned long long>(), n, 0u};
