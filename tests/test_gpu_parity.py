@@ -960,7 +960,7 @@ def test_heatmap_matches_oracle_bit_for_bit(scene_name, bvh):
 
 # ------------------------------------------------------------------ GPU BVH builder (8f rank 4)
 @pytest.mark.parametrize("builder", ["lbvh", "ploc"])
-@pytest.mark.parametrize("name", ["one sphere", "two prims", "disney_spheres", "big_mesh", "config4"])
+@pytest.mark.parametrize("name", ["one sphere", "two prims", "coincident", "disney_spheres", "big_mesh", "config4"])
 def test_gpu_builders_give_a_valid_tree_and_the_same_picture(name, builder):
     """vimg_hip_build_lbvh (Morton order + radix tree + bottom-up boxes, one primitive per leaf) and
     vimg_hip_build_ploc (locally-ordered clustering + SAH leaves of up to 8), emitted in the
@@ -969,7 +969,20 @@ def test_gpu_builders_give_a_valid_tree_and_the_same_picture(name, builder):
     the picture does not depend on which tree was built (ties aside)."""
     from test_host_and_abi import _check_tree
     from vimg_amd import hip, host
-    if name in ("one sphere", "two prims"):
+    if name == "coincident":
+        # 40 spheres around ONE centre (all Morton codes equal, every split plane degenerate: the builders
+        # fall back to splits by position) beside a light and a floor sphere
+        s = host.HostScene()
+        m = s.add_material("lambertian", tex=s.add_texture_const((0.6, 0.7, 0.5)))
+        lt = s.add_material("diffuse_light", emit=(6, 6, 6))
+        for k in range(40):
+            s.add_sphere((0.0, 0.5, 0.0), 0.3 + 0.01 * k, m)
+        s.add_sphere((0.5, 3.0, 0.5), 0.8, lt)
+        s.add_sphere((0.0, -100.0, 0.0), 100.0, m)
+        s.set_camera((0, 1.5, 6), (0, 0.6, 0), (0, 1, 0), 40, (40, 32))
+        s.set_render_defaults("mis", 4, 8)
+        s.build_bvh()
+    elif name in ("one sphere", "two prims"):
         s = host.HostScene()
         m = s.add_material("lambertian", tex=s.add_texture_const((0.7, 0.6, 0.5)))
         lt = s.add_material("diffuse_light", emit=(5, 5, 5))
