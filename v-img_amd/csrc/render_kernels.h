@@ -810,9 +810,11 @@ VD void sphere_hit_info(const DScene& g, uint32_t sphere, const TravRay& r, uint
     h.tv = normalize(cross(normal, tangent));
   }
   if constexpr (TEX) {
+    // (the same fields in the same order as the triangle's record: the compiler sinks the two branches' last
+    // stores into one, and a store through a choice of two fields keeps both fields in scratch memory)
+    h.curvature = 1.f / radius;
     h.prim_area = 1.f;
     h.tex_area = 0.000001f;
-    h.curvature = 1.f / radius;
   }
 }
 template <bool TEX>
