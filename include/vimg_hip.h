@@ -107,7 +107,10 @@ int64_t vimg_hip_shard_pixels(const VimgDeviceScene* scene, const VimgRenderPara
  *                       ([local_tile][ty*8+tx]); assemble with vimg_hip_assemble_shards().
  *  stream    : a hipStream_t cast to void*, or NULL for the library's own stream.
  *  stats     : optional HOST pointer, filled when the call returns.
- * The call enqueues the kernels and waits for them (the reference call is blocking too). */
+ * The call enqueues the kernels and waits for them (the reference call is blocking too).
+ * Limit of one launch: the rings of a compute unit count the rays it queues in 32 bits - about 2^31 per
+ * launch, i.e. the whole 1800x800 frame of disney_spheres up to ~60 000 samples per pixel (the reference's
+ * scenes ask for 512-2048); beyond it the launch ends with VIMG_E_DEVICE and says so. */
 int vimg_hip_render(VimgDeviceScene* scene, const VimgRenderParams* params, void* d_out_rgb,
                     void* stream, VimgRenderStats* stats);
 

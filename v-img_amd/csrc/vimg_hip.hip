@@ -827,9 +827,15 @@ int check_kernel_error(VimgDeviceScene* s) {
   if (s->d_stage_ctl)
     HIP_TRY(hipMemcpy(&stage_err, &static_cast<StageCtl*>(s->d_stage_ctl)->error.v, sizeof(stage_err), hipMemcpyDeviceToHost));
   if (words[1] != 0) HIP_TRY(hipMemset(s->d_counter + 1, 0, sizeof(unsigned int)));   // read once
-  if (words[1] != 0 || stage_err != 0)
-    return fail(VIMG_E_DEVICE, "render kernel watchdog: a wave waited for work that never came "
-                               "(the frame is incomplete), code " + std::to_string(words[1] | (stage_err << 8)));
+  if (words[1] != 0 || stage_err != 0) {
+    // bits of the launch's error word (render_cu_kernel.h: raise): 1 a wave found nothing to do for ten seconds
+    // while slots were live, 2 a group lock timed out (development build), 4 a ring entry was reserved and never
+    // written, 8 a compute unit queued more than 2^31 rays or slots in one launch
+    const std::string what = (words[1] & 8u) ? "a compute unit queued more than 2^31 rays in one launch: render fewer samples per launch"
+                                             : "a wave waited for work that never came";
+    return fail(VIMG_E_DEVICE, "render kernel watchdog: " + what + " (the frame is incomplete), code " +
+                                   std::to_string(words[1] | (stage_err << 8)));
+  }
   return VIMG_OK;
 }
 
