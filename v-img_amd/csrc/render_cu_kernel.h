@@ -20,7 +20,7 @@
 //    atomic OR on the slot's flag word tells) hands the slot to the vertex queue of its class.
 //  * the pool is the CU's (up to 16 waves share it), so batches are whatever 64 slots the CU has
 //    waiting, and a thin shard's pixels all sit in LDS slots at once.
-// Measured and NOT kept (profiles/r3_cu/experiments.txt; all bit-identical):
+// Measured and NOT kept (DESIGN.md 4.4 has the whole list, profiles/r3_cu/sweeps_raw.txt the runs; all bit-identical):
 //  * a second, urgent set of rings for slots whose pixel lags behind the pool's mean sample index:
 //    the last pixel of an eighth of config 2 finished no earlier (19.2 against 18.4 ms at 64 spp - it
 //    is bound by the service time of its hops, 9 Principled vertices per sample, not by queueing)
