@@ -148,6 +148,7 @@ struct RenderArgs {
   uint32_t cu_patience;             // CU scheduler: looks in vain after which a wave takes a partial batch of any size
   uint32_t cu_join;                 // CU scheduler: queued rays at which a walking wave that holds none starts to walk (fewer: after cu_patience looks)
   uint32_t cu_sleep;                // CU scheduler: s_sleep argument of a wave that found nothing to do
+  uint32_t cu_watchdog;             // CU scheduler: a wave idle for longer than this (2^20 ticks of the 100 MHz clock) while slots are live gives up
   uint32_t cu_magic_v, cu_shift_v;  // CU scheduler: n / pool_slots == mulhi(n, magic) >> shift (n < 2^31)
   uint32_t cu_magic_w, cu_shift_w;  // ... n / (2 * pool_slots)
   int32_t single_x, single_y;       // trace_pixel mode when >= 0

@@ -1256,11 +1256,12 @@ render_cu_kernel(const CuKArgs ka) {
     // for ten seconds while slots are live is waiting for something that will not come; it raises
     // the launch's error word so that a scheduling bug ends as VIMG_E_DEVICE instead of a hung GPU.
     // The one legitimate long wait is for a pixel's previous SEGMENT in another workgroup's hands, and a
-    // segment's time grows with its samples: 50 ms for each of them on top (hundreds of their paths).
+    // segment's time grows with its samples: 50 ms for each of them on top (hundreds of their paths; the
+    // limit comes from the host, in units of 2^20 ticks).
     if ((polls & 255u) == 0u) {
       const unsigned long long now = __builtin_amdgcn_s_memrealtime();
       if (idle_since == 0) idle_since = now;
-      else if (now - idle_since > 1000000000ull + 5000000ull * seg_len) {
+      else if (static_cast<uint32_t>((now - idle_since) >> 20) > A.cu_watchdog) {
         if (lane == 0) raise(1u);
         break;
       }

@@ -450,6 +450,7 @@ LaunchCfg make_launch_cu(const VimgDeviceScene* s, const VimgRenderParams* p, in
   // segments: as the group build of render_pool4_kernel (the tail of a frame is one segment long)
   a.pool_segments = 1;
   a.pool_seg_len = p->samples;
+  a.cu_watchdog = static_cast<uint32_t>(1000000000ull >> 20);
   if (sx < 0) {
     const uint64_t in_flight = uint64_t(c.grid) * slots;
     const double gens = double(items) / double(in_flight);
@@ -462,6 +463,7 @@ LaunchCfg make_launch_cu(const VimgDeviceScene* s, const VimgRenderParams* p, in
     const uint32_t len = std::max<uint32_t>((p->samples + k - 1) / k, 1u);
     a.pool_seg_len = len;
     a.pool_segments = std::max<uint32_t>((p->samples + len - 1) / len, 1u);
+    a.cu_watchdog = static_cast<uint32_t>(std::min<uint64_t>((1000000000ull + 5000000ull * len) >> 20, 0x7fffffffull));   // 10 s + 50 ms per sample of a segment
   }
   return c;
 }
