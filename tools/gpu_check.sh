@@ -32,6 +32,8 @@ for step in "$@"; do
       rc=$?; [ $rc -eq 0 ] || exit $rc
       (cd /tmp && timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT --output-format csv -d "$OUT/pmc5" -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu --spp 512 > "$OUT/pmc5.log" 2>&1)
       rc=$?; [ $rc -eq 0 ] || exit $rc
+      (cd /tmp && timeout -k 10 400 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH --output-format csv -d "$OUT/pmc6" -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu --spp 512 > "$OUT/pmc6.log" 2>&1)
+      rc=$?; [ $rc -eq 0 ] || exit $rc
       python3 "$R/tools/pmc_summary.py" "$OUT" "$OUT/pmc1.log" > "$OUT/pmc_summary.json" ;;
   esac
 done

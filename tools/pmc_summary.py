@@ -42,6 +42,8 @@ if g("SQ_ACTIVE_INST_VALU"):
     d["wait_any_share"] = g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES")
 if g("SQ_LDS_IDX_ACTIVE"):
     d["lds_bank_conflict_share"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
+if g("SQC_ICACHE_REQ"):
+    d["icache_miss_share"] = g("SQC_ICACHE_MISSES") / g("SQC_ICACHE_REQ")
 n = max(launches.values()) if launches else 0
 if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None and n:
     d["hbm_side_bytes_per_launch"] = (g("FETCH_SIZE") * 2 + g("WRITE_SIZE")) * 1024 / n
